@@ -1,0 +1,144 @@
+/*
+ * msmp_pde.h -- C-ABI of libmsmp_pde.so: the MI355X (gfx950) message-passing rollout path of MSMP-PDE.
+ *
+ * This is the drop-in boundary.  The reference (Leqr/MSMP-PDE, 100 % Python)
+ * reaches native code for this path only through third-party Python extensions (torch_geometric,
+ * torch_scatter, torch_cluster, lem_cuda); each entry point below names the reference call site it
+ * replaces (paths relative to the reference root).  Conventions:
+ *
+ *   - plain C: raw DEVICE pointers + sizes, no torch / C++ types;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is stream-ordered,
+ *     never synchronises the device and never allocates: scratch comes from `workspace`;
+ *   - all matrices row-major; float tensors are fp32 unless the name says f64; indices are int32 on
+ *     the compute path (int64 only where the reference's `edge_index` is produced / consumed);
+ *   - returns MSMP_OK (0) or a negative MSMP_ERR_*; msmp_last_error() gives the text; never throws;
+ *   - hidden width is fixed at MSMP_HIDDEN = 128 (hidden_features, experiments/models_gnn.py:158).
+ *
+ * Layer weights are passed as a "packed layer" blob made by msmp_pack_layer_f32 from the reference's
+ * eight nn.Linear tensors ([out,in] layout); see DESIGN.md section 3 for the blob layout.
+ */
+#ifndef MSMP_PDE_H
+#define MSMP_PDE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSMP_HIDDEN 128
+#define MSMP_MAX_VARS 8          /* len(eq_variables) + 1 <= 8 */
+
+#define MSMP_OK               0
+#define MSMP_ERR_ARG         -1  /* null pointer / bad size */
+#define MSMP_ERR_UNSUPPORTED -2  /* shape outside what the kernels are built for */
+#define MSMP_ERR_WORKSPACE   -3  /* workspace too small */
+#define MSMP_ERR_HIP         -4  /* HIP runtime error (text in msmp_last_error) */
+
+/* flags for msmp_node_update_f32 / msmp_mp_layer_f32 */
+#define MSMP_LAYER_RESIDUAL_SWISH 0  /* GNN_Layer.update    experiments/models_gnn.py:77-86  : x + Swish(W4 . + b4) */
+#define MSMP_LAYER_LIN            1  /* GNN_LayerLin.update experiments/models_gnn.py:140-149: W4 . + b4           */
+
+typedef void* msmp_stream_t;
+
+int msmp_version(void);
+const char* msmp_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weights
+ * ------------------------------------------------------------------------------------------- */
+/* Number of floats of one packed layer for a given u-feature width `tw` (25; 50 for *2D) and
+ * variable count `nv` = len(eq_variables)+1. */
+int64_t msmp_packed_layer_floats(int tw, int nv);
+
+/* Pack message_net_1/2 and update_net_1/2 of one GNN_Layer / GNN_LayerLin
+ * (experiments/models_gnn.py:47-58, 112-121) into the kernel layout.  w1 [128, 256+tw+1+nv],
+ * w2 [128,128], w3 [128, 256+nv], w4 [128,128], b* [128]; all device pointers, reference layout. */
+int msmp_pack_layer_f32(const float* w1, const float* b1, const float* w2, const float* b2,
+                        const float* w3, const float* b3, const float* w4, const float* b4,
+                        int tw, int nv, float* packed_out, msmp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph structure (rows G1 of SURVEY section 8a)
+ * ------------------------------------------------------------------------------------------- */
+/* CSR-by-target from the reference's edge_index [2,E] int64 (row 0 source j, row 1 target i;
+ * torch_geometric MessagePassing flow='source_to_target', experiments/models_gnn.py:65,128).
+ * Writes rowptr [N+1], col [E] (source of each edge, grouped by ascending target, original relative
+ * order kept inside a target) and tgt [E] (target of each CSR slot).  If the input is already grouped
+ * by ascending target (what the graph builders emit) no sort is needed; otherwise a stable device
+ * sort runs in `workspace` (size from msmp_build_csr_workspace_bytes). */
+size_t msmp_build_csr_workspace_bytes(int64_t n_edges, int64_t n_nodes);
+int msmp_build_csr(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes,
+                   int32_t* rowptr_out, int32_t* col_out, int32_t* tgt_out,
+                   void* workspace, size_t workspace_bytes, msmp_stream_t stream);
+
+/* torch_cluster.radius_graph(x, r, batch, loop=False, max_num_neighbors) as called at
+ * common/utils.py:368, on `dim`-column float64 coordinates x [N,dim]; graph g owns nodes
+ * graph_ptr[g]..graph_ptr[g+1]-1.  Pair (j -> i) kept iff same graph, i != j and squared distance
+ * < r*r (float64, strict); at most max_neighbors sources per target, lowest index first.
+ * Two calls: _count writes rowptr [N+1] (in-degree prefix sums; E = rowptr[N]); _fill writes
+ * edge_index [2,E] int64 in canonical order (ascending target, then ascending source). */
+int msmp_radius_graph_count_f64(const double* x, int dim, const int32_t* graph_ptr, int64_t n_graphs,
+                                int64_t n_nodes, double r, int max_neighbors,
+                                int32_t* rowptr_out, msmp_stream_t stream);
+int msmp_radius_graph_fill_f64(const double* x, int dim, const int32_t* graph_ptr, int64_t n_graphs,
+                               int64_t n_nodes, double r, int max_neighbors, const int32_t* rowptr,
+                               int64_t n_edges, int64_t* edge_index_out, msmp_stream_t stream);
+
+/* torch_cluster.knn_graph(x, k, batch, loop=False) as called at common/utils.py:377,380: per target
+ * its min(k, n_g-1) nearest same-graph nodes, ascending float64 squared distance, ties -> lower
+ * index.  rowptr [N+1] and edge_index [2,E] are both written; E = sum_g n_g*min(k, n_g-1) is known
+ * to the caller from graph sizes and passed as n_edges (writes past it are suppressed). */
+int msmp_knn_graph_f64(const double* x, int dim, const int32_t* graph_ptr, int64_t n_graphs,
+                       int64_t n_nodes, int k, int64_t n_edges, int32_t* rowptr_out,
+                       int64_t* edge_index_out, msmp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Message-passing layer pieces (rows L1-L5)
+ * ------------------------------------------------------------------------------------------- */
+/* L1  GNN_Layer.message / GNN_LayerLin.message, experiments/models_gnn.py:69-75 / 132-138, with the
+ * PyG gathers of propagate (:65,128) fused in:
+ *   msg[e] = Swish(W2 Swish(W1 [h_i, h_j, u_i-u_j, pos_i-pos_j, vars_i] + b1) + b2),
+ * i = tgt[e], j = col[e].  h [N,128], u [N,tw], pos [N] (= pos_x), vars [N,nv], msg_out [E,128]. */
+int msmp_edge_mlp_f32(const float* h, const float* u, const float* pos, const float* vars,
+                      const int32_t* tgt, const int32_t* col, int64_t n_nodes, int64_t n_edges,
+                      int tw, int nv, const float* packed, float* msg_out, msmp_stream_t stream);
+
+/* L2  PyG aggr='mean' (torch_scatter scatter-mean; experiments/models_gnn.py:42,107):
+ *   agg[i] = sum_{e in CSR row i} msg[e] / max(deg_i, 1), fixed summation order (CSR order). */
+int msmp_scatter_mean_f32(const float* msg, const int32_t* rowptr, int64_t n_nodes,
+                          float* agg_out, msmp_stream_t stream);
+
+/* L3  update(): experiments/models_gnn.py:77-86 (MSMP_LAYER_RESIDUAL_SWISH) / 140-149 (MSMP_LAYER_LIN)
+ * on [h, agg, vars]. */
+int msmp_node_update_f32(const float* h, const float* agg, const float* vars, int64_t n_nodes, int nv,
+                         const float* packed, int mode, float* out, msmp_stream_t stream);
+
+/* L4  torch_geometric.nn.InstanceNorm(128) (affine=False, no running stats), experiments/models_gnn.py:
+ * 59,66,122,129: per graph g and channel (x-mean)/sqrt(biased var + eps). */
+int msmp_instance_norm_f32(const float* x, const int32_t* graph_ptr, int64_t n_graphs, float eps,
+                           float* out, msmp_stream_t stream);
+
+/* L4+L5  gate blend, experiments/models_gnn.py:1204-1207 / 1365-1368 (models_gnn2D.py:267-269, 438-441):
+ *   tau = sigmoid(InstanceNorm(gate_pre));  out = (1-tau)*h + tau*Swish(InstanceNorm(main_pre)). */
+int msmp_gate_blend_f32(const float* h, const float* gate_pre, const float* main_pre,
+                        const int32_t* graph_ptr, int64_t n_graphs, float eps, float* out,
+                        msmp_stream_t stream);
+
+/* One whole message-passing layer: GNN_Layer.forward / GNN_LayerLin.forward
+ * (experiments/models_gnn.py:61-67 / 124-130) = L1 -> L2 -> L3 -> L4; when packed_gate != NULL the
+ * gated pair of one iteration of the solver loop (L5) is evaluated and blended.  h_out may not alias h.
+ * Workspace size from msmp_mp_layer_workspace_bytes. */
+size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges, int gated);
+int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars,
+                      const int32_t* rowptr, const int32_t* col, const int32_t* tgt,
+                      const int32_t* graph_ptr, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                      int tw, int nv, const float* packed_main, const float* packed_gate, int mode,
+                      float eps, float* h_out, void* workspace, size_t workspace_bytes,
+                      msmp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSMP_PDE_H */

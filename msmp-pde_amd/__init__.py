@@ -1,0 +1,12 @@
+"""msmp-pde_amd: the MI355X-native message-passing rollout path of MSMP-PDE.
+
+Host-side mirror of the reference's module interface over the C-ABI library libmsmp_pde.so
+(include/msmp_pde.h).  See DESIGN.md.  Import as `msmp_pde_amd` (alias module at the repo root).
+"""
+from ._lib import lib, MsmpError, LIB_PATH                                    # noqa: F401
+from .pde import CE, WE, AD                                                   # noqa: F401
+from .graph import Data, GraphCreator, GraphStructure, structure_of, radius_graph, knn_graph   # noqa: F401
+from .layers import Swish, GNN_Layer, GNN_LayerLin, mp_layer                  # noqa: F401
+from .lem import LEM                                                          # noqa: F401
+from .solvers import (MP_PDE_Solver, MP_PDE_SolverGated, MP_PDE_SolverLEMLinGated, MP_PDE_Solver2D,   # noqa: F401
+                      MP_PDE_Solver2DGated, MP_PDE_Solver2DLEMLinGated, MODEL_NAMES)

@@ -1,0 +1,73 @@
+"""ctypes binding of libmsmp_pde.so (include/msmp_pde.h).  There is no fallback: if the library is
+missing or a call fails, this raises."""
+import ctypes
+import os
+from ctypes import c_int, c_int64, c_size_t, c_void_p, c_float, c_double, c_char_p
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, 'libmsmp_pde.so')
+
+MSMP_LAYER_RESIDUAL_SWISH = 0
+MSMP_LAYER_LIN = 1
+MSMP_MAX_VARS = 8
+HIDDEN = 128
+
+# name -> (restype, argtypes); must list every symbol include/msmp_pde.h declares
+SIGNATURES = {
+    'msmp_version': (c_int, []),
+    'msmp_last_error': (c_char_p, []),
+    'msmp_packed_layer_floats': (c_int64, [c_int, c_int]),
+    'msmp_pack_layer_f32': (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p, c_void_p]),
+    'msmp_build_csr_workspace_bytes': (c_size_t, [c_int64, c_int64]),
+    'msmp_build_csr': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'msmp_radius_graph_count_f64': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_double, c_int, c_void_p, c_void_p]),
+    'msmp_radius_graph_fill_f64': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_double, c_int, c_void_p, c_int64,
+                                           c_void_p, c_void_p]),
+    'msmp_knn_graph_f64': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    'msmp_edge_mlp_f32': (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'msmp_scatter_mean_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    'msmp_node_update_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    'msmp_instance_norm_f32': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    'msmp_gate_blend_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    'msmp_mp_layer_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
+    'msmp_mp_layer_f32': (c_int, [c_void_p] * 8 + [c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int,
+                                                   c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+class MsmpError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MsmpError(f'{LIB_PATH} not found: build it with `python msmp-pde_amd/build.py` '
+                            '(or __graft_entry__.build()); there is no CPU fallback')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)        # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().msmp_last_error()
+        raise MsmpError(f'{what} failed with code {rc}: {msg.decode() if msg else ""}')
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

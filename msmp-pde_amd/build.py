@@ -1,0 +1,51 @@
+"""Build libmsmp_pde.so (HIP, gfx950 only) in-tree with hipcc.  No torch involved: the library is a
+plain C-ABI shared object (include/msmp_pde.h); the Python host binds it with ctypes."""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, 'csrc')
+LIB = os.path.join(PKG, 'libmsmp_pde.so')
+
+SOURCES = {  # file -> extra flags
+    'mlp_kernels.hip': [],
+    'aux_kernels.hip': [],
+    'graph_kernels.hip': ['-ffp-contract=off'],   # float64 distance compares must round like the host's
+}
+COMMON = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
+          '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    headers.append(os.path.join(ROOT, 'include', 'msmp_pde.h'))
+    objs = []
+    for src, extra in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace('.hip', '.o'))
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc] + COMMON + extra + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

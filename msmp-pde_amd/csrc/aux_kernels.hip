@@ -1,0 +1,251 @@
+// HBM-bound pieces of the message-passing layer: weight packing, mean aggregation (row L2),
+// InstanceNorm (row L4), gate blend (row L5), and the whole-layer entry point that chains the pieces.
+#include <stdarg.h>
+#include "msmp_common.h"
+
+namespace msmp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return MSMP_ERR_HIP;
+    }
+    return MSMP_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// pack
+// ----------------------------------------------------------------------------------------------
+struct PackArgs {
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
+    int tw, nv;
+    float* out;
+};
+
+__global__ void pack_layer_kernel(PackArgs a) {
+    const PackedLayout L = packed_layout(a.tw, a.nv);
+    const int k1 = 2 * H + a.tw + 1 + a.nv;   // in-features of message_net_1
+    const int k3 = 2 * H + a.nv;              // in-features of update_net_1
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < L.total; p += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (p < L.w4) {                       // w3 chunks
+            const int64_t o = p - L.w3;
+            const int ch = (int)(o / CHUNK_FLOATS), row = (int)(o % CHUNK_FLOATS) / KC, kk = (int)(o % KC);
+            v = a.w3[(size_t)row * k3 + ch * KC + kk];
+        } else if (p < L.b1) {                // w4 chunks
+            const int64_t o = p - L.w4;
+            const int ch = (int)(o / CHUNK_FLOATS), row = (int)(o % CHUNK_FLOATS) / KC, kk = (int)(o % KC);
+            v = a.w4[(size_t)row * H + ch * KC + kk];
+        } else if (p < L.b2) v = a.b1[p - L.b1];
+        else if (p < L.b3) v = a.b2[p - L.b2];
+        else if (p < L.b4) v = a.b3[p - L.b3];
+        else if (p < L.w3v) v = a.b4[p - L.b4];
+        else if (p < L.w1) {                  // variables columns of update_net_1
+            const int64_t o = p - L.w3v;
+            const int row = (int)(o / MSMP_MAX_VARS), vv = (int)(o % MSMP_MAX_VARS);
+            v = vv < a.nv ? a.w3[(size_t)row * k3 + 2 * H + vv] : 0.f;
+        } else if (p < L.w2) {                // w1 chunks, zero padded past k1
+            const int64_t o = p - L.w1;
+            const int ch = (int)(o / CHUNK_FLOATS), row = (int)(o % CHUNK_FLOATS) / KC, kk = (int)(o % KC);
+            const int k = ch * KC + kk;
+            v = k < k1 ? a.w1[(size_t)row * k1 + k] : 0.f;
+        } else {                              // w2 chunks
+            const int64_t o = p - L.w2;
+            const int ch = (int)(o / CHUNK_FLOATS), row = (int)(o % CHUNK_FLOATS) / KC, kk = (int)(o % KC);
+            v = a.w2[(size_t)row * H + ch * KC + kk];
+        }
+        a.out[p] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// L2: CSR segmented mean.  32 lanes x 16 B cover one 512-B message row; a wave reduces two nodes at a
+// time, a 256-thread block eight.  Rows of one node are summed in CSR order (fixed -> bitwise
+// reproducible); loads are independent of each other, so the wave keeps `deg` rows in flight.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scatter_mean_kernel(const float* __restrict__ msg, const int* __restrict__ rowptr,
+                                                           long n_nodes, float* __restrict__ agg) {
+    const int sub = threadIdx.x & 31;
+    const long node = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (node >= n_nodes) return;
+    const int r0 = rowptr[node], r1 = rowptr[node + 1];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* p = reinterpret_cast<const f32x4*>(msg) + (size_t)r0 * (H / 4) + sub;
+    int r = r0;
+    for (; r + 4 <= r1; r += 4, p += 4 * (H / 4)) {
+        const f32x4 a0 = p[0], a1 = p[H / 4], a2 = p[2 * (H / 4)], a3 = p[3 * (H / 4)];
+        s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; r < r1; ++r, p += H / 4) s += p[0];
+    const float inv = 1.0f / (float)max(r1 - r0, 1);
+    reinterpret_cast<f32x4*>(agg)[(size_t)node * (H / 4) + sub] = s * inv;
+}
+
+// ----------------------------------------------------------------------------------------------
+// L4 / L5: per-graph statistics.  One 256-thread workgroup per graph: thread = (16-B channel group
+// cg = tid & 31, row slice rs = tid >> 5); two passes (mean, then centred second moment), as PyG's
+// InstanceNorm does; a graph's rows (nx x 512 B ~ 51 KB) stay in L2 between the passes.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 block_colsum(f32x4 v, f32x4* red, int cg, int rs) {
+    red[rs * 32 + cg] = v;
+    __syncthreads();
+    f32x4 s = red[cg];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += red[i * 32 + cg];
+    __syncthreads();
+    return s;
+}
+
+__device__ __forceinline__ void graph_stats(const float* __restrict__ x, int n0, int n1, int cg, int rs, f32x4* red,
+                                            float eps, f32x4& mean, f32x4& rstd) {
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int r = n0 + rs; r < n1; r += 8) s += xp[(size_t)r * (H / 4) + cg];
+    const float inv = 1.0f / (float)max(n1 - n0, 1);
+    mean = block_colsum(s, red, cg, rs) * inv;
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    for (int r = n0 + rs; r < n1; r += 8) {
+        const f32x4 d = xp[(size_t)r * (H / 4) + cg] - mean;
+        q += d * d;
+    }
+    const f32x4 var = block_colsum(q, red, cg, rs) * inv;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) rstd[m] = 1.0f / sqrtf(var[m] + eps);
+}
+
+__global__ __launch_bounds__(256) void instance_norm_kernel(const float* __restrict__ x, const int* __restrict__ graph_ptr,
+                                                            float eps, float* __restrict__ out) {
+    __shared__ f32x4 red[256];
+    const int cg = threadIdx.x & 31, rs = threadIdx.x >> 5;
+    const int n0 = graph_ptr[blockIdx.x], n1 = graph_ptr[blockIdx.x + 1];
+    f32x4 mean, rstd;
+    graph_stats(x, n0, n1, cg, rs, red, eps, mean, rstd);
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x);
+    f32x4* op = reinterpret_cast<f32x4*>(out);
+    for (int r = n0 + rs; r < n1; r += 8) op[(size_t)r * (H / 4) + cg] = (xp[(size_t)r * (H / 4) + cg] - mean) * rstd;
+}
+
+__global__ __launch_bounds__(256) void gate_blend_kernel(const float* __restrict__ h, const float* __restrict__ gate,
+                                                         const float* __restrict__ mainp, const int* __restrict__ graph_ptr,
+                                                         float eps, float* __restrict__ out) {
+    __shared__ f32x4 red[256];
+    const int cg = threadIdx.x & 31, rs = threadIdx.x >> 5;
+    const int n0 = graph_ptr[blockIdx.x], n1 = graph_ptr[blockIdx.x + 1];
+    f32x4 gm, gr, mm, mr;
+    graph_stats(gate, n0, n1, cg, rs, red, eps, gm, gr);
+    graph_stats(mainp, n0, n1, cg, rs, red, eps, mm, mr);
+    const f32x4* hp = reinterpret_cast<const f32x4*>(h);
+    const f32x4* gp = reinterpret_cast<const f32x4*>(gate);
+    const f32x4* mp = reinterpret_cast<const f32x4*>(mainp);
+    f32x4* op = reinterpret_cast<f32x4*>(out);
+    for (int r = n0 + rs; r < n1; r += 8) {
+        const size_t o = (size_t)r * (H / 4) + cg;
+        const f32x4 g = (gp[o] - gm) * gr, mnv = (mp[o] - mm) * mr, hv = hp[o];
+        f32x4 res;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float tau = sigmoidf_(g[m]);
+            res[m] = (1.0f - tau) * hv[m] + tau * swishf(mnv[m]);
+        }
+        op[o] = res;
+    }
+}
+
+}  // namespace msmp
+
+using namespace msmp;
+
+extern "C" int msmp_version(void) { return 100; }
+extern "C" const char* msmp_last_error(void) { return g_err; }
+
+extern "C" int64_t msmp_packed_layer_floats(int tw, int nv) {
+    if (tw <= 0 || nv < 1 || nv > MSMP_MAX_VARS) return -1;
+    return packed_layout(tw, nv).total;
+}
+
+extern "C" int msmp_pack_layer_f32(const float* w1, const float* b1, const float* w2, const float* b2,
+                                   const float* w3, const float* b3, const float* w4, const float* b4,
+                                   int tw, int nv, float* packed_out, msmp_stream_t stream) {
+    MSMP_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && w4 && b4 && packed_out, MSMP_ERR_ARG, "msmp_pack_layer_f32: null pointer");
+    MSMP_REQUIRE(tw > 0 && nv >= 1 && nv <= MSMP_MAX_VARS, MSMP_ERR_ARG, "msmp_pack_layer_f32: bad tw=%d nv=%d", tw, nv);
+    PackArgs a{w1, b1, w2, b2, w3, b3, w4, b4, tw, nv, packed_out};
+    hipLaunchKernelGGL(pack_layer_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("pack_layer_kernel");
+}
+
+extern "C" int msmp_scatter_mean_f32(const float* msg, const int32_t* rowptr, int64_t n_nodes, float* agg_out,
+                                     msmp_stream_t stream) {
+    MSMP_REQUIRE(rowptr && agg_out, MSMP_ERR_ARG, "msmp_scatter_mean_f32: null pointer");
+    MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31), MSMP_ERR_ARG, "msmp_scatter_mean_f32: bad n_nodes");
+    const unsigned grid = (unsigned)((n_nodes + 7) / 8);
+    hipLaunchKernelGGL(scatter_mean_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, msg, rowptr, (long)n_nodes, agg_out);
+    return check_launch("scatter_mean_kernel");
+}
+
+extern "C" int msmp_instance_norm_f32(const float* x, const int32_t* graph_ptr, int64_t n_graphs, float eps, float* out,
+                                      msmp_stream_t stream) {
+    MSMP_REQUIRE(x && graph_ptr && out, MSMP_ERR_ARG, "msmp_instance_norm_f32: null pointer");
+    MSMP_REQUIRE(n_graphs > 0 && n_graphs < (1L << 31), MSMP_ERR_ARG, "msmp_instance_norm_f32: bad n_graphs");
+    hipLaunchKernelGGL(instance_norm_kernel, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, x, graph_ptr, eps, out);
+    return check_launch("instance_norm_kernel");
+}
+
+extern "C" int msmp_gate_blend_f32(const float* h, const float* gate_pre, const float* main_pre, const int32_t* graph_ptr,
+                                   int64_t n_graphs, float eps, float* out, msmp_stream_t stream) {
+    MSMP_REQUIRE(h && gate_pre && main_pre && graph_ptr && out, MSMP_ERR_ARG, "msmp_gate_blend_f32: null pointer");
+    MSMP_REQUIRE(n_graphs > 0 && n_graphs < (1L << 31), MSMP_ERR_ARG, "msmp_gate_blend_f32: bad n_graphs");
+    hipLaunchKernelGGL(gate_blend_kernel, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, h, gate_pre, main_pre,
+                       graph_ptr, eps, out);
+    return check_launch("gate_blend_kernel");
+}
+
+// Workspace of the chained layer: msg [E,128] | agg [N,128] | pre_main [N,128] | pre_gate [N,128] (gated only)
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges, int gated) {
+    const size_t msg = align256((size_t)n_edges * H * sizeof(float));
+    const size_t nod = align256((size_t)n_nodes * H * sizeof(float));
+    return msg + nod * (gated ? 3 : 2);
+}
+
+extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars,
+                                 const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const int32_t* graph_ptr,
+                                 int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int tw, int nv,
+                                 const float* packed_main, const float* packed_gate, int mode, float eps, float* h_out,
+                                 void* workspace, size_t workspace_bytes, msmp_stream_t stream) {
+    MSMP_REQUIRE(h && u && pos && vars && rowptr && col && tgt && graph_ptr && packed_main && h_out && workspace,
+                 MSMP_ERR_ARG, "msmp_mp_layer_f32: null pointer");
+    MSMP_REQUIRE(h_out != h, MSMP_ERR_ARG, "msmp_mp_layer_f32: h_out may not alias h");
+    const int gated = packed_gate != nullptr;
+    MSMP_REQUIRE(!gated || mode == MSMP_LAYER_LIN, MSMP_ERR_ARG, "msmp_mp_layer_f32: the gated pair uses GNN_LayerLin layers");
+    MSMP_REQUIRE(workspace_bytes >= msmp_mp_layer_workspace_bytes(n_nodes, n_edges, gated), MSMP_ERR_WORKSPACE,
+                 "msmp_mp_layer_f32: workspace %zu < %zu", workspace_bytes, msmp_mp_layer_workspace_bytes(n_nodes, n_edges, gated));
+    char* ws = (char*)workspace;
+    float* msg = (float*)ws;
+    ws += align256((size_t)n_edges * H * sizeof(float));
+    const size_t nod = align256((size_t)n_nodes * H * sizeof(float));
+    float* agg = (float*)ws;
+    float* pre_main = (float*)(ws + nod);
+    float* pre_gate = (float*)(ws + 2 * nod);
+    int rc;
+    if (gated) {
+        if ((rc = msmp_edge_mlp_f32(h, u, pos, vars, tgt, col, n_nodes, n_edges, tw, nv, packed_gate, msg, stream))) return rc;
+        if ((rc = msmp_scatter_mean_f32(msg, rowptr, n_nodes, agg, stream))) return rc;
+        if ((rc = msmp_node_update_f32(h, agg, vars, n_nodes, nv, packed_gate, MSMP_LAYER_LIN, pre_gate, stream))) return rc;
+    }
+    if ((rc = msmp_edge_mlp_f32(h, u, pos, vars, tgt, col, n_nodes, n_edges, tw, nv, packed_main, msg, stream))) return rc;
+    if ((rc = msmp_scatter_mean_f32(msg, rowptr, n_nodes, agg, stream))) return rc;
+    if ((rc = msmp_node_update_f32(h, agg, vars, n_nodes, nv, packed_main, mode, pre_main, stream))) return rc;
+    if (gated) return msmp_gate_blend_f32(h, pre_gate, pre_main, graph_ptr, n_graphs, eps, h_out, stream);
+    return msmp_instance_norm_f32(pre_main, graph_ptr, n_graphs, eps, h_out, stream);
+}

@@ -1,0 +1,74 @@
+// Shared device/host helpers for libmsmp_pde.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "msmp_pde.h"
+
+namespace msmp {
+
+constexpr int H = MSMP_HIDDEN;          // hidden width
+constexpr int KC = 32;                  // k-chunk of a weight matrix staged through LDS
+constexpr int LDW = 36;                 // LDS row stride (dwords) of a staged chunk: 4*odd, so the
+                                        // 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots
+constexpr int CHUNK_FLOATS = H * KC;    // one packed chunk: [128 out][32 k]
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// Packed layer blob (floats).  Chunks are [128 out][32 k] row-major, k ascending, zero padded.
+// Sections whose size does not depend on tw come first, so the node kernels need no tw:
+//   w3 (8 chunks: h | agg columns of update_net_1) | w4 (4 chunks) | b1 b2 b3 b4 ([128] each) |
+//   w3v [128][MSMP_MAX_VARS] (variables columns of update_net_1) |
+//   w1 (nc1 chunks: h_i | h_j | u_i-u_j, p_i-p_j, vars_i, 0-pad) | w2 (4 chunks)
+// w4 directly follows w3 and w2 directly follows w1: the staging pipeline prefetches across the seam.
+struct PackedLayout {
+    int nc1;        // chunks of W1 (4 h_i + 4 h_j + tail chunks)
+    int64_t w3, w4, b1, b2, b3, b4, w3v, w1, w2, total;
+};
+
+__host__ __device__ inline int tail_chunks(int tw, int nv) { return (tw + 1 + nv + KC - 1) / KC; }
+
+__host__ __device__ inline PackedLayout packed_layout(int tw, int nv) {
+    PackedLayout L;
+    L.nc1 = 8 + tail_chunks(tw, nv);
+    int64_t o = 0;
+    L.w3 = o; o += 8 * CHUNK_FLOATS;
+    L.w4 = o; o += 4 * CHUNK_FLOATS;
+    L.b1 = o; o += H;
+    L.b2 = o; o += H;
+    L.b3 = o; o += H;
+    L.b4 = o; o += H;
+    L.w3v = o; o += H * MSMP_MAX_VARS;
+    L.w1 = o; o += (int64_t)L.nc1 * CHUNK_FLOATS;
+    L.w2 = o; o += 4 * CHUNK_FLOATS;
+    L.total = o;
+    return L;
+}
+
+// Swish(x) = x * sigmoid(x) (experiments/models_gnn.py:20-21) = x / (1 + 2^(-x*log2 e)).
+// v_exp_f32 and v_rcp_f32 are 1-ulp; measured against the float64 oracle in tests/test_gpu_kernels.py.
+__device__ __forceinline__ float swishf(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896340736f);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float sigmoidf_(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896340736f);
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// Row of a 32x32 MFMA accumulator register: D[row][col = lane & 31].
+__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+}  // namespace msmp
+
+#define MSMP_REQUIRE(cond, code, ...)          \
+    do {                                       \
+        if (!(cond)) {                         \
+            msmp::set_error(__VA_ARGS__);      \
+            return (code);                     \
+        }                                      \
+    } while (0)

@@ -1,0 +1,248 @@
+"""Graph side of the hot path: the `Data` container, device-side edge_index builders, the
+CSR-by-target structure the kernels consume, and a vectorised mirror of the reference's GraphCreator.
+
+Reference: common/utils.py:267-471 (GraphCreator), torch_cluster.radius_graph / knn_graph call sites
+common/utils.py:368,377,380, torch_geometric.data.Data (:382).  SURVEY.md section 8a rows G1, G2, R1.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, current_stream
+
+
+class Data(object):
+    """Attribute bag standing in for torch_geometric.data.Data (common/utils.py:382-385):
+    x [N,Tw], y, pos [N,2] (t, x), batch [N] int64, edge_index [2,E] int64, plus the per-experiment
+    [N,1] parameter columns.  `.to(device)` moves every tensor attribute, like PyG's."""
+
+    def __init__(self, x=None, edge_index=None, **kwargs):
+        self.x = x
+        self.edge_index = edge_index
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def keys(self):
+        return [k for k in self.__dict__ if not k.startswith('_')]
+
+    def to(self, device):
+        for k in list(self.__dict__):
+            v = self.__dict__[k]
+            if torch.is_tensor(v):
+                self.__dict__[k] = v.to(device)
+            elif isinstance(v, GraphStructure):
+                self.__dict__[k] = None if torch.device(device) != v.rowptr.device else v
+        return self
+
+
+class GraphStructure(object):
+    """What the kernels need of a batch of graphs, built once and reused over the rollout (the
+    reference reuses edge_index and batch in create_next_graph, common/utils.py:431-471):
+    CSR by target (rowptr [N+1], col [E] = source, tgt [E]) and graph_ptr [B+1], all int32 on device."""
+
+    def __init__(self, edge_index, batch, n_nodes):
+        dev = edge_index.device
+        if dev.type != 'cuda':
+            raise _lib.MsmpError('GraphStructure needs device tensors (HIP path only, no CPU fallback)')
+        L = lib()
+        self.n_nodes = int(n_nodes)
+        self.n_edges = int(edge_index.shape[1])
+        ei = edge_index.contiguous()
+        if ei.dtype != torch.int64:
+            ei = ei.long()
+        counts = torch.bincount(batch, minlength=int(batch[-1].item()) + 1 if batch.numel() else 1)
+        self.n_graphs = int(counts.numel())
+        self.graph_ptr = torch.zeros(self.n_graphs + 1, dtype=torch.int32, device=dev)
+        self.graph_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        self.rowptr = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
+        self.col = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
+        self.tgt = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
+        ws_bytes = L.msmp_build_csr_workspace_bytes(self.n_edges, self.n_nodes)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(L.msmp_build_csr(ptr(ei), self.n_edges, self.n_nodes, ptr(self.rowptr), ptr(self.col), ptr(self.tgt),
+                               ptr(ws), ws_bytes, current_stream()), 'msmp_build_csr')
+        self._key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
+                     batch.data_ptr(), batch._version)
+
+    def matches(self, edge_index, batch):
+        return self._key == (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
+                             batch.data_ptr(), batch._version)
+
+
+def structure_of(data):
+    """GraphStructure of a Data object, cached on it (rebuilt if edge_index / batch changed)."""
+    gs = getattr(data, '_msmp_structure', None)
+    if gs is None or not gs.matches(data.edge_index, data.batch):
+        gs = GraphStructure(data.edge_index, data.batch, data.x.shape[0])
+        data._msmp_structure = gs
+    return gs
+
+
+def _graph_ptr_from_sizes(sizes, device):
+    gp = torch.zeros(len(sizes) + 1, dtype=torch.int32)
+    gp[1:] = torch.cumsum(torch.as_tensor(sizes, dtype=torch.int64), 0).to(torch.int32)
+    return gp.to(device)
+
+
+def radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, sizes=None):
+    """Device-side torch_cluster.radius_graph (call site common/utils.py:368).  x: [N] or [N,dim]
+    float64 on the GPU; `batch` sorted ascending (or `sizes` = nodes per graph).  Returns edge_index
+    [2,E] int64 in canonical order: ascending target, then ascending source.  Bit-exact contract:
+    pair kept iff (x_i-x_j)^2 summed over dims in float64 < r*r."""
+    assert not loop
+    x2 = x.reshape(x.shape[0], -1).to(torch.float64).contiguous()
+    dev = x2.device
+    n = x2.shape[0]
+    if sizes is None:
+        sizes = torch.bincount(batch).tolist() if batch is not None else [n]
+    gp = _graph_ptr_from_sizes(sizes, dev)
+    L = lib()
+    st = current_stream()
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    check(L.msmp_radius_graph_count_f64(ptr(x2), x2.shape[1], ptr(gp), len(sizes), n, float(r), int(max_num_neighbors),
+                                        ptr(rowptr), st), 'msmp_radius_graph_count_f64')
+    e = int(rowptr[-1].item())
+    ei = torch.empty((2, e), dtype=torch.int64, device=dev)
+    check(L.msmp_radius_graph_fill_f64(ptr(x2), x2.shape[1], ptr(gp), len(sizes), n, float(r), int(max_num_neighbors),
+                                       ptr(rowptr), e, ptr(ei), st), 'msmp_radius_graph_fill_f64')
+    return ei
+
+
+def knn_graph(x, k, batch=None, loop=False, sizes=None):
+    """Device-side torch_cluster.knn_graph (call sites common/utils.py:377,380): per target its k nearest
+    same-graph nodes, ascending float64 squared distance, ties -> lower index."""
+    assert not loop
+    x2 = x.reshape(x.shape[0], -1).to(torch.float64).contiguous()
+    dev = x2.device
+    n = x2.shape[0]
+    if sizes is None:
+        sizes = torch.bincount(batch).tolist() if batch is not None else [n]
+    gp = _graph_ptr_from_sizes(sizes, dev)
+    e = sum(s * min(k, s - 1) for s in sizes)
+    L = lib()
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    ei = torch.empty((2, e), dtype=torch.int64, device=dev)
+    check(L.msmp_knn_graph_f64(ptr(x2), x2.shape[1], ptr(gp), len(sizes), n, int(k), e, ptr(rowptr), ptr(ei),
+                               current_stream()), 'msmp_knn_graph_f64')
+    return ei
+
+
+def torch_time_axis(pde):
+    """t = torch.linspace(tmin, tmax, nt) in float64 on the CPU, exactly the values the reference
+    builds at common/utils.py:340,456 (ATen's CPU linspace; computed there so pos[:,0] is bit-identical)."""
+    return torch.linspace(pde.tmin, pde.tmax, pde.grid_size[0], dtype=torch.float64)
+
+
+class GraphCreator(object):
+    """Vectorised mirror of common/utils.py:267-471.  Same constructor and methods; the per-node and
+    per-sample Python `torch.cat` loops (utils.py:349-362, 390-426, 459-467) become index arithmetic, the
+    tensors are assembled directly on `device`, and edge_index comes from the device builders above
+    (or is passed in / cached: the grid is the same for every batch)."""
+
+    def __init__(self, pde, neighbors=2, time_window=5, t_resolution=250, x_resolution=100, device=None):
+        assert isinstance(neighbors, int) and isinstance(time_window, int)
+        self.pde = pde
+        self.n = neighbors
+        self.tw = time_window
+        self.t_res = t_resolution
+        self.x_res = x_resolution
+        self.device = device
+        self._edge_cache = {}
+
+    def to(self, device):
+        self.device = device
+        return self
+
+    # -- common/utils.py:300-317
+    def create_data(self, datapoints, steps):
+        steps_t = torch.as_tensor(steps, device=datapoints.device)
+        b = torch.arange(datapoints.shape[0], device=datapoints.device)[:, None]
+        win = torch.arange(self.tw, device=datapoints.device)[None, :]
+        data = datapoints[b, steps_t[:, None] - self.tw + win]
+        labels = datapoints[b, steps_t[:, None] + win]
+        return data, labels
+
+    def _flatten(self, block):
+        """[B,tw,nx] -> [B*nx, tw]; AD: [B,tw,2,nx] -> [B*nx, 2*tw] component-major (utils.py:350-357)."""
+        if f'{self.pde}' == 'AD':
+            b, tw, c, nx = block.shape
+            return block.permute(0, 3, 2, 1).reshape(b * nx, c * tw)
+        b, tw, nx = block.shape
+        return block.permute(0, 2, 1).reshape(b * nx, tw)
+
+    def build_edge_index(self, x0, bsz, device):
+        """Row G1.  x0: the [nx] float64 grid of one sample (the reference uses x[0] for all, utils.py:359,366)."""
+        name = f'{self.pde}'
+        nx = x0.shape[0]
+        x0c = x0.detach().to('cpu', torch.float64).contiguous()
+        key = (name, self.n, bsz, nx, str(device), bool(getattr(self.pde, 'untructured_grid', False)),
+               hash(x0c.numpy().tobytes()))
+        if key in self._edge_cache:
+            return self._edge_cache[key]
+        sizes = [nx] * bsz
+        if name in ('CE', 'KF', 'KS', 'AD'):
+            if name == 'AD' and getattr(self.pde, 'untructured_grid', False):
+                # utils.py:343-346: periodic embedding, evaluated on the CPU in float64 like the reference
+                xx = 2 * math.pi * x0c / (torch.max(x0c) - 1e-3)
+                x_per = torch.stack([torch.cos(xx), torch.sin(xx)], 1)
+                ei = knn_graph(x_per.repeat(bsz, 1).to(device), self.n, sizes=sizes)
+            else:
+                dx = float(x0c[1] - x0c[0])
+                ei = radius_graph(x0c.repeat(bsz).to(device), self.n * dx + 0.0001, sizes=sizes)
+        elif name == 'WE':
+            ei = knn_graph(x0c.repeat(bsz).to(device), self.n, sizes=sizes)
+        else:
+            raise ValueError(f'unknown pde {name}')
+        self._edge_cache = {key: ei}
+        return ei
+
+    # -- common/utils.py:320-428
+    def create_graph(self, data, labels, x, variables, steps, edge_index=None):
+        device = self.device if self.device is not None else data.device
+        nt, nx = self.pde.grid_size[0], self.pde.grid_size[1]
+        bsz = data.shape[0]
+        t = torch_time_axis(self.pde)
+        steps_t = torch.as_tensor(steps, dtype=torch.long)
+        u = self._flatten(data.to(device))
+        y = self._flatten(labels.to(device))
+        x0 = x[0]
+        x_pos = x0.to(device).repeat(bsz)
+        t_pos = t[steps_t].to(device).repeat_interleave(nx)
+        batch = torch.arange(bsz, device=device).repeat_interleave(nx)
+        if edge_index is None:
+            edge_index = self.build_edge_index(x0, bsz, device)
+        graph = Data(x=u, edge_index=edge_index)
+        graph.y = y
+        graph.pos = torch.cat((t_pos[:, None].to(x_pos.dtype), x_pos[:, None]), 1)
+        graph.batch = batch
+
+        def col(name, sign=1.0):
+            v = torch.as_tensor(variables[name]).to(device)
+            return (sign * v)[batch][:, None]
+
+        name = f'{self.pde}'
+        if name == 'CE':           # utils.py:388-397; beta is stored negated (:392)
+            graph.alpha, graph.beta, graph.gamma = col('alpha'), col('beta', -1.0), col('gamma')
+        elif name == 'KF':
+            graph.r, graph.D = col('r'), col('D')
+        elif name == 'WE':
+            graph.bc_left, graph.bc_right, graph.c = col('bc_left'), col('bc_right'), col('c')
+        elif name == 'AD':
+            graph.a, graph.b = col('a'), col('b')
+        return graph
+
+    # -- common/utils.py:431-471
+    def create_next_graph(self, graph, pred, labels, steps):
+        keep = 2 * self.tw if f'{self.pde}' == 'AD' else self.tw
+        if pred.shape[1] == keep and graph.x.shape[1] == keep:
+            graph.x = pred.to(graph.x.dtype)         # cat(x, pred)[:, keep:] == pred
+        else:
+            graph.x = torch.cat((graph.x, pred.to(graph.x.dtype)), 1)[:, keep:]
+        nx = self.pde.grid_size[1]
+        t = torch_time_axis(self.pde)
+        steps_t = torch.as_tensor(steps, dtype=torch.long)
+        device = graph.x.device
+        graph.y = self._flatten(labels.to(device))
+        graph.pos[:, 0] = t[steps_t].to(device).repeat_interleave(nx).to(graph.pos.dtype)
+        return graph

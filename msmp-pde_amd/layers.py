@@ -1,0 +1,133 @@
+"""Message-passing layers with the reference's module / parameter names, running on the HIP kernels.
+
+Reference: experiments/models_gnn.py:12-21 (Swish), 23-86 (GNN_Layer), 88-149 (GNN_LayerLin).
+state_dict keys are identical (`message_net_1.0.weight` [128, 2*128+tw+1+nv], `message_net_2.0.*`,
+`update_net_1.0.weight` [128, 2*128+nv], `update_net_2.0.*`; InstanceNorm has no parameters), so
+reference checkpoints load unchanged.  Parameters are created in float32 whatever the default dtype
+is (the reference's import side effect makes it float64, temporal/solvers.py:10).
+"""
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import lib, check, ptr, current_stream, HIDDEN
+from .graph import GraphStructure
+
+
+class Swish(nn.Module):
+    """x * sigmoid(beta x); experiments/models_gnn.py:12-21."""
+
+    def __init__(self, beta=1):
+        super().__init__()
+        self.beta = beta
+
+    def forward(self, x):
+        return x * torch.sigmoid(self.beta * x)
+
+
+def _linear(i, o):
+    return nn.Linear(i, o, dtype=torch.float32)
+
+
+class _Workspace(object):
+    """Grow-only scratch buffer per device, shared by all layers (the C-ABI never allocates)."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, nbytes, device):
+        buf = cls._bufs.get(device)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            cls._bufs[device] = buf
+        return buf
+
+
+class _MPLayerBase(nn.Module):
+    MODE = None
+
+    def __init__(self, in_features, out_features, hidden_features, time_window, n_variables):
+        super().__init__()
+        if not (in_features == out_features == hidden_features == HIDDEN):
+            raise ValueError(f'the HIP kernels are built for hidden width {HIDDEN}')
+        if not 1 <= n_variables <= _lib.MSMP_MAX_VARS:
+            raise ValueError(f'n_variables must be in 1..{_lib.MSMP_MAX_VARS}')
+        self.in_features, self.out_features, self.hidden_features = in_features, out_features, hidden_features
+        self.time_window, self.n_variables = time_window, n_variables
+        self.message_net_1 = nn.Sequential(_linear(2 * in_features + time_window + 1 + n_variables, hidden_features), Swish())
+        self.message_net_2 = nn.Sequential(_linear(hidden_features, hidden_features), Swish())
+        self.update_net_1 = nn.Sequential(_linear(in_features + hidden_features + n_variables, hidden_features), Swish())
+        self._make_update_net_2(hidden_features, out_features)
+        self._packed = None
+        self._packed_key = None
+
+    def _params8(self):
+        return (self.message_net_1[0].weight, self.message_net_1[0].bias, self.message_net_2[0].weight,
+                self.message_net_2[0].bias, self.update_net_1[0].weight, self.update_net_1[0].bias,
+                self.update_net_2[0].weight, self.update_net_2[0].bias)
+
+    def packed(self):
+        """Kernel-layout weight blob (msmp_pack_layer_f32), re-packed only when a parameter changed."""
+        ps = self._params8()
+        key = tuple((p.data_ptr(), p._version, str(p.device), p.dtype) for p in ps)
+        if key != self._packed_key:
+            dev = ps[0].device
+            if dev.type != 'cuda':
+                raise _lib.MsmpError('layer parameters must be on the GPU (HIP path only, no CPU fallback)')
+            L = lib()
+            n = L.msmp_packed_layer_floats(self.time_window, self.n_variables)
+            blob = torch.empty(n, dtype=torch.float32, device=dev)
+            f = [p.detach().to(torch.float32).contiguous() for p in ps]
+            check(L.msmp_pack_layer_f32(*[ptr(t) for t in f], self.time_window, self.n_variables, ptr(blob),
+                                        current_stream()), 'msmp_pack_layer_f32')
+            self._packed, self._packed_key = blob, key
+        return self._packed
+
+    def forward(self, x, u, pos, variables, edge_index, batch, structure=None):
+        """Same signature as the reference's layer forward (experiments/models_gnn.py:61-67 / 124-130);
+        `structure` lets the solver pass the cached CSR instead of rebuilding it from edge_index."""
+        if structure is None:
+            structure = GraphStructure(edge_index, batch, x.shape[0])
+        return mp_layer(x, u, pos, variables, structure, self, None)
+
+
+class GNN_Layer(_MPLayerBase):
+    """experiments/models_gnn.py:23-86: Swish on the last linear and residual x + update."""
+    MODE = _lib.MSMP_LAYER_RESIDUAL_SWISH
+
+    def _make_update_net_2(self, h, o):
+        self.update_net_2 = nn.Sequential(_linear(h, o), Swish())
+
+
+class GNN_LayerLin(_MPLayerBase):
+    """experiments/models_gnn.py:88-149: no final activation, no residual."""
+    MODE = _lib.MSMP_LAYER_LIN
+
+    def _make_update_net_2(self, h, o):
+        self.update_net_2 = nn.Sequential(_linear(h, o))
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5):
+    """One message-passing layer (or one gated pair) on the device through msmp_mp_layer_f32.
+    h [N,128], u [N,Tw], pos_x [N,1] or [N], variables [N,nv]: float32 CUDA tensors."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in main.parameters()):
+        raise NotImplementedError('backward kernels are not built yet (DESIGN.md, "next" rows): run the HIP '
+                                  'message-passing path under torch.no_grad()')
+    L = lib()
+    gs = structure
+    h, u, pos_x, variables = _f32c(h), _f32c(u), _f32c(pos_x).reshape(-1), _f32c(variables)
+    n = h.shape[0]
+    assert n == gs.n_nodes and h.shape[1] == HIDDEN and u.shape[1] == main.time_window
+    assert variables.shape[1] == main.n_variables and pos_x.numel() == n
+    out = torch.empty_like(h)
+    gated = gate is not None
+    ws_bytes = L.msmp_mp_layer_workspace_bytes(n, gs.n_edges, int(gated))
+    ws = _Workspace.get(ws_bytes, h.device)
+    check(L.msmp_mp_layer_f32(ptr(h), ptr(u), ptr(pos_x), ptr(variables), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt),
+                              ptr(gs.graph_ptr), n, gs.n_edges, gs.n_graphs, main.time_window, main.n_variables,
+                              ptr(main.packed()), ptr(gate.packed()) if gated else None, main.MODE, eps, ptr(out),
+                              ptr(ws), ws.numel(), current_stream()), 'msmp_mp_layer_f32')
+    return out

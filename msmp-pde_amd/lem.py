@@ -1,0 +1,64 @@
+"""LEM ("Long Expressive Memory") node encoder in PyTorch-ROCm.
+
+The reference reaches an absent CUDA extension here (`import lem_cuda`, experiments/models_gnn.py:8,
+285-342); BASELINE.json's north_star keeps the encoder in PyTorch, so this is a pure-torch
+restatement of the recurrence with the reference's parameter names (`rnn.weights` [3H, ninp+H],
+`rnn.weights_lin_z` [H, ninp+H], `rnn.bias` [3H], `rnn.bias_lin_z` [H]) and init
+U(-1/sqrt(H), 1/sqrt(H)) (:318-321), dt = 1 (:334).  PARITY UNPINNED: the column order inside
+lem_cuda cannot be confirmed offline; it follows the published LEM cell:
+    X = [y, x_t]; g = X W^T + b -> (g1, g2, g3); dt_bar = dt s(g1); dt_ = dt s(g2)
+    z <- (1-dt_) z + dt_ tanh(g3);  y <- (1-dt_bar) y + dt_bar tanh([z, x_t] Wz^T + bz)
+"""
+import math
+
+import torch
+from torch import nn
+
+
+class LEMcuda(nn.Module):
+    """Parameter holder named like the reference's (experiments/models_gnn.py:305-330)."""
+
+    def __init__(self, ninp, nhid, dt):
+        super().__init__()
+        self.ninp, self.nhid, self.dt = ninp, nhid, float(dt)
+        self.weights = nn.Parameter(torch.empty(3 * nhid, ninp + nhid, dtype=torch.float32))
+        self.weights_lin_z = nn.Parameter(torch.empty(nhid, ninp + nhid, dtype=torch.float32))
+        self.bias = nn.Parameter(torch.empty(3 * nhid, dtype=torch.float32))
+        self.bias_lin_z = nn.Parameter(torch.empty(nhid, dtype=torch.float32))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.nhid)
+        for w in self.parameters():
+            w.data.uniform_(-stdv, +stdv)
+
+    def forward(self, inputs):
+        """inputs [T, N, ninp] -> final y [N, nhid]."""
+        t_len, n, _ = inputs.shape
+        nh = self.nhid
+        y = inputs.new_zeros(n, nh)
+        z = inputs.new_zeros(n, nh)
+        wy, wx = self.weights[:, :nh].t().contiguous(), self.weights[:, nh:].t().contiguous()
+        zy, zx = self.weights_lin_z[:, :nh].t().contiguous(), self.weights_lin_z[:, nh:].t().contiguous()
+        # input projections for all steps at once (the recurrent part stays sequential)
+        gx = torch.matmul(inputs, wx) + self.bias          # [T, N, 3H]
+        lx = torch.matmul(inputs, zx) + self.bias_lin_z    # [T, N, H]
+        for t in range(t_len):
+            g = torch.addmm(gx[t], y, wy)
+            dt_bar = self.dt * torch.sigmoid(g[:, :nh])
+            dt_ = self.dt * torch.sigmoid(g[:, nh:2 * nh])
+            z = (1.0 - dt_) * z + dt_ * torch.tanh(g[:, 2 * nh:])
+            y = (1.0 - dt_bar) * y + dt_bar * torch.tanh(torch.addmm(lx[t], z, zy))
+        return y
+
+
+class LEM(nn.Module):
+    """experiments/models_gnn.py:333-342: returns all_y[-1]."""
+
+    def __init__(self, ninp, nhid, dt=1.):
+        super().__init__()
+        self.ninp, self.nhid = ninp, nhid
+        self.rnn = LEMcuda(ninp, nhid, dt)
+
+    def forward(self, inputs):
+        return self.rnn(inputs)

@@ -1,0 +1,165 @@
+"""Drop-in solver classes: same constructor, `forward(data)` signature, `repr() == 'GNN'` and
+state_dict key names as the reference, with the message-passing stack on the HIP kernels.
+
+Reference classes:
+  MP_PDE_Solver               experiments/models_gnn.py:151-281
+  MP_PDE_SolverGated          experiments/models_gnn.py:1067-1218
+  MP_PDE_SolverLEMLinGated    experiments/models_gnn.py:1220-1377      ("MSMP-PDE", train.py:52-56)
+  MP_PDE_Solver2D             experiments/models_gnn2D.py:17-141
+  MP_PDE_Solver2DGated        experiments/models_gnn2D.py:143-288
+  MP_PDE_Solver2DLEMLinGated  experiments/models_gnn2D.py:290-458      ("MSMP-PDE2D", train.py:116-120)
+Encoder (embedding MLP / LEM), `double_mlp` and the decoder CNN stay in PyTorch-ROCm (BASELINE.json
+north_star); the L x [message -> mean -> update -> InstanceNorm (-> gate blend)] loop is
+msmp_mp_layer_f32.  `pde.L`, `pde.tmax`, `pde.dt` are read at call time (they are mutated after
+construction, experiments/train.py:355-358).  Compute dtype is float32; the result is returned in
+the dtype of `data.x`.
+"""
+import torch
+from torch import nn
+
+from .graph import structure_of
+from .layers import GNN_Layer, GNN_LayerLin, Swish, mp_layer
+from .lem import LEM
+
+_DECODER = {20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}   # models_gnn.py:210-224; models_gnn2D.py:79-88
+
+
+def _lin(i, o):
+    return nn.Linear(i, o, dtype=torch.float32)
+
+
+class _SolverBase(nn.Module):
+    TWO_D = False
+    GATED = False
+    LEM_ENCODER = False
+    LAYER = GNN_Layer
+
+    def __init__(self, pde, time_window=25, hidden_features=128, hidden_layer=6, eq_variables={}, save_state=None):
+        super().__init__()
+        allowed = (25, 50) if self.TWO_D else (20, 25, 50)
+        assert time_window in allowed
+        if save_state:
+            raise NotImplementedError('the state-saving LEMS variant is out of scope (SURVEY.md section 2)')
+        self.pde = pde
+        self.out_features = time_window
+        self.hidden_features = hidden_features
+        self.hidden_layer = hidden_layer
+        self.time_window = time_window
+        self.eq_variables = eq_variables
+        comps = 2 if self.TWO_D else 1
+        nv = len(eq_variables) + 1
+        mk = lambda: self.LAYER(in_features=hidden_features, hidden_features=hidden_features,
+                                out_features=hidden_features, time_window=comps * time_window, n_variables=nv)
+        self.gnn_layers = nn.ModuleList(mk() for _ in range(hidden_layer))
+        if self.GATED:
+            self.gnn_layers_gate = nn.ModuleList(mk() for _ in range(hidden_layer))
+            self.swish = Swish()
+        if self.LEM_ENCODER:
+            self.embedding_lem = LEM(2 + len(eq_variables) + comps, hidden_features)
+            self.lemoutput_mlp = nn.Sequential(_lin(hidden_features, hidden_features), Swish(),
+                                               _lin(hidden_features, hidden_features), Swish())
+        else:
+            self.embedding_mlp = nn.Sequential(_lin(comps * time_window + 2 + len(eq_variables), hidden_features), Swish(),
+                                               _lin(hidden_features, hidden_features), Swish())
+        k1, s1, k2 = _DECODER[time_window]
+        if self.TWO_D:
+            self.double_mlp = nn.Sequential(_lin(hidden_features, 2 * hidden_features), Swish(),
+                                            nn.Unflatten(1, (2, hidden_features)))
+        self.output_mlp = nn.Sequential(nn.Conv1d(comps, 8, k1, stride=s1, dtype=torch.float32), Swish(),
+                                        nn.Conv1d(8, comps, k2, stride=1, dtype=torch.float32))
+
+    def __repr__(self):
+        return 'GNN'     # every helper of the reference dispatches on this (train_helper.py:99,110,124,...)
+
+    # -- feature preparation -----------------------------------------------------------------
+    def _variables(self, data, pos_t):
+        ev = self.eq_variables
+        cols = [pos_t]
+        if self.TWO_D:      # models_gnn2D.py:112-116 -- NB 'b' divides data.a (reference behaviour, kept)
+            if 'a' in ev:
+                cols.append(data.a / ev['a'])
+            if 'b' in ev:
+                cols.append(data.a / ev['b'])
+        else:               # models_gnn.py:250-266
+            for k in ('alpha', 'beta', 'gamma'):
+                if k in ev:
+                    cols.append(getattr(data, k) / ev[k])
+            for k in ('bc_left', 'bc_right'):
+                if k in ev:
+                    cols.append(getattr(data, k))
+            for k in ('c', 'D', 'r'):
+                if k in ev:
+                    cols.append(getattr(data, k) / ev[k])
+        return torch.cat([c.to(pos_t.dtype) for c in cols], -1)
+
+    def _encode(self, u, pos_x, pos_t, variables, dt):
+        if not self.LEM_ENCODER:        # models_gnn.py:269-270
+            return self.embedding_mlp(torch.cat((u, pos_x, variables), -1))
+        tw = self.time_window
+        n = u.shape[0]
+        if self.TWO_D:                  # models_gnn2D.py:421-436
+            ts = dt.view(1, tw) + pos_t
+            lem_in = torch.stack([pos_x.expand(n, tw), u[:, :tw], u[:, tw:], ts], -1)       # [N, tw, 4]
+            lem_in = torch.cat((lem_in, variables[:, None, 1:].expand(n, tw, variables.shape[1] - 1)), -1)
+        else:                           # models_gnn.py:1356-1363
+            t_len = u.shape[1]
+            lem_in = torch.cat((pos_x[:, None, :].expand(n, t_len, 1), u[:, :, None],
+                                variables[:, None, :].expand(n, t_len, variables.shape[1])), -1)
+        h = self.embedding_lem(lem_in.permute(1, 0, 2).contiguous())
+        return self.lemoutput_mlp(h)
+
+    # -- forward -------------------------------------------------------------------------------
+    def forward(self, data):
+        u_in = data.x
+        pos = data.pos
+        pos_x = (pos[:, 1][:, None] / self.pde.L)
+        pos_t = (pos[:, 0][:, None] / self.pde.tmax)
+        variables = self._variables(data, pos_t).float()
+        pos_x, pos_t = pos_x.float(), pos_t.float()
+        u = u_in.float().contiguous()
+        gs = structure_of(data)
+        tw = self.time_window
+        dt = torch.cumsum(torch.ones(tw, dtype=torch.float32, device=u.device) * self.pde.dt, 0)
+
+        h = self._encode(u, pos_x, pos_t, variables, dt)
+        for i in range(self.hidden_layer):
+            gate = self.gnn_layers_gate[i] if self.GATED else None
+            h = mp_layer(h, u, pos_x, variables, gs, self.gnn_layers[i], gate)
+
+        if self.TWO_D:                  # models_gnn2D.py:125-141
+            diff = self.output_mlp(self.double_mlp(h))
+            out = (u.view(-1, 2, tw) + dt.view(1, 1, tw) * diff).flatten(1, 2)
+        else:                           # models_gnn.py:275-279
+            diff = self.output_mlp(h[:, None]).squeeze(1)
+            out = u[:, -1:] + dt.view(1, tw) * diff
+        return out.to(u_in.dtype)
+
+
+class MP_PDE_Solver(_SolverBase):
+    pass
+
+
+class MP_PDE_SolverGated(_SolverBase):
+    GATED, LAYER = True, GNN_LayerLin
+
+
+class MP_PDE_SolverLEMLinGated(_SolverBase):
+    GATED, LEM_ENCODER, LAYER = True, True, GNN_LayerLin
+
+
+class MP_PDE_Solver2D(_SolverBase):
+    TWO_D = True
+
+
+class MP_PDE_Solver2DGated(_SolverBase):
+    TWO_D, GATED, LAYER = True, True, GNN_LayerLin
+
+
+class MP_PDE_Solver2DLEMLinGated(_SolverBase):
+    TWO_D, GATED, LEM_ENCODER, LAYER = True, True, True, GNN_LayerLin
+
+
+MODEL_NAMES = {   # experiments/train.py:34-183 getModel names -> class
+    'MP-PDE': MP_PDE_Solver, 'Gated': MP_PDE_SolverGated, 'MSMP-PDE': MP_PDE_SolverLEMLinGated,
+    'MP-PDE2D': MP_PDE_Solver2D, 'Gated2D': MP_PDE_Solver2DGated, 'MSMP-PDE2D': MP_PDE_Solver2DLEMLinGated,
+}

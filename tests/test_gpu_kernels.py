@@ -1,0 +1,230 @@
+"""GPU parity tests (run with -m gpu on the MI355X): every C-ABI entry point against the float64
+oracle, on the committed golden inputs and on seeded random inputs (ragged graphs, zero in-degree
+nodes, unsorted edges).  Bars: bit-exact for index work; fp32 kernels within the tolerance written
+next to each assert (the end-to-end bar of BASELINE.json is 1e-5 on the solver output)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import msmp_oracle as O
+from helpers import load, sd_of, graph_of
+
+pytestmark = pytest.mark.gpu
+
+H = 128
+
+
+@pytest.fixture(scope='module')
+def mp():
+    import msmp_pde_amd
+    assert torch.cuda.is_available()
+    msmp_pde_amd.lib()
+    return msmp_pde_amd
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rand_layer_sd(rng, tw, nv, scale=1.0):
+    k1, k3 = 2 * H + tw + 1 + nv, 2 * H + nv
+    u = lambda *s, fan: (rng.uniform(-1, 1, s) / np.sqrt(fan) * scale).astype(np.float32)
+    return {'message_net_1.0.weight': u(H, k1, fan=k1), 'message_net_1.0.bias': u(H, fan=k1),
+            'message_net_2.0.weight': u(H, H, fan=H), 'message_net_2.0.bias': u(H, fan=H),
+            'update_net_1.0.weight': u(H, k3, fan=k3), 'update_net_1.0.bias': u(H, fan=k3),
+            'update_net_2.0.weight': u(H, H, fan=H), 'update_net_2.0.bias': u(H, fan=H)}
+
+
+def pack(mp, sd, tw, nv):
+    L = mp.lib()
+    from msmp_pde_amd._lib import check, ptr, current_stream
+    n = L.msmp_packed_layer_floats(tw, nv)
+    blob = torch.empty(n, dtype=torch.float32, device='cuda')
+    keys = ['message_net_1.0.weight', 'message_net_1.0.bias', 'message_net_2.0.weight', 'message_net_2.0.bias',
+            'update_net_1.0.weight', 'update_net_1.0.bias', 'update_net_2.0.weight', 'update_net_2.0.bias']
+    ts = [dev(sd[k], torch.float32) for k in keys]
+    check(L.msmp_pack_layer_f32(*[ptr(t) for t in ts], tw, nv, ptr(blob), current_stream()), 'pack')
+    torch.cuda.synchronize()
+    return blob
+
+
+def random_graph_batch(rng, sizes, max_deg=6, shuffle=False, isolated=True):
+    """Ragged batch: graph g has sizes[g] nodes, each node a random in-degree in [0, max_deg] from its own graph."""
+    src, dst, batch = [], [], []
+    off = 0
+    for g, n in enumerate(sizes):
+        for i in range(n):
+            d = int(rng.integers(0 if isolated else 1, max_deg + 1))
+            if n > 1 and d:
+                js = rng.choice([j for j in range(n) if j != i], size=min(d, n - 1), replace=False)
+                src.extend((js + off).tolist())
+                dst.extend([i + off] * len(js))
+        batch.extend([g] * n)
+        off += n
+    ei = np.array([src, dst], dtype=np.int64)
+    if shuffle:
+        ei = ei[:, rng.permutation(ei.shape[1])]
+    return ei, np.array(batch, dtype=np.int64)
+
+
+def layer_inputs(rng, n, tw, nv):
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+    return f(n, H), f(n, tw), rng.uniform(0, 1, (n, 1)).astype(np.float32), rng.uniform(0, 1, (n, nv)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_pack_layer_layout(mp):
+    """The packed blob holds exactly the reference tensors, chunked [128][32] and zero padded."""
+    rng = np.random.default_rng(0)
+    for tw, nv in ((25, 2), (50, 3), (20, 4)):
+        sd = rand_layer_sd(rng, tw, nv)
+        blob = pack(mp, sd, tw, nv).cpu().numpy()
+        nc1 = 8 + (tw + 1 + nv + 31) // 32
+        o = 0
+        w3 = blob[o:o + 8 * 4096].reshape(8, H, 32); o += 8 * 4096
+        w4 = blob[o:o + 4 * 4096].reshape(4, H, 32); o += 4 * 4096
+        b = blob[o:o + 4 * H].reshape(4, H); o += 4 * H
+        w3v = blob[o:o + H * 8].reshape(H, 8); o += H * 8
+        w1 = blob[o:o + nc1 * 4096].reshape(nc1, H, 32); o += nc1 * 4096
+        w2 = blob[o:o + 4 * 4096].reshape(4, H, 32); o += 4 * 4096
+        assert o == blob.size
+        un = lambda c: np.transpose(c, (1, 0, 2)).reshape(H, -1)
+        k1 = 2 * H + tw + 1 + nv
+        assert np.array_equal(un(w1)[:, :k1], sd['message_net_1.0.weight']) and not un(w1)[:, k1:].any()
+        assert np.array_equal(un(w2), sd['message_net_2.0.weight'])
+        assert np.array_equal(un(w3), sd['update_net_1.0.weight'][:, :2 * H])
+        assert np.array_equal(w3v[:, :nv], sd['update_net_1.0.weight'][:, 2 * H:]) and not w3v[:, nv:].any()
+        assert np.array_equal(un(w4), sd['update_net_2.0.weight'])
+        for i, k in enumerate(('message_net_1.0.bias', 'message_net_2.0.bias', 'update_net_1.0.bias', 'update_net_2.0.bias')):
+            assert np.array_equal(b[i], sd[k])
+
+
+@pytest.mark.parametrize('tw,nv,sizes,shuffle', [(25, 2, [100, 100], False), (50, 3, [100, 37, 1, 64], True),
+                                                 (20, 4, [5, 300, 17], True), (25, 1, [129], False)])
+def test_layer_pieces_vs_oracle(mp, tw, nv, sizes, shuffle):
+    """L1-L5 piece by piece on ragged random graphs (zero in-degree nodes, a 1-node graph, unsorted edges)."""
+    from msmp_pde_amd._lib import check, ptr, current_stream
+    from msmp_pde_amd.graph import GraphStructure
+    L = mp.lib()
+    rng = np.random.default_rng(hash((tw, nv, len(sizes))) % 2 ** 31)
+    ei, batch = random_graph_batch(rng, sizes, shuffle=shuffle)
+    n, e = len(batch), ei.shape[1]
+    h, u, pos, var = layer_inputs(rng, n, tw, nv)
+    sd = rand_layer_sd(rng, tw, nv, scale=2.0)
+    p = O.layer_params({k: v.astype(np.float64) for k, v in sd.items()}, '')
+    h64, u64, pos64, var64 = (a.astype(np.float64) for a in (h, u, pos, var))
+    blob = pack(mp, sd, tw, nv)
+    gs = GraphStructure(dev(ei), dev(batch), n)
+    torch.cuda.synchronize()
+
+    # CSR: grouped by ascending target, stable inside a target (bit-exact)
+    order = np.argsort(ei[1], kind='stable')
+    assert np.array_equal(gs.tgt.cpu().numpy()[:e], ei[1][order])
+    assert np.array_equal(gs.col.cpu().numpy()[:e], ei[0][order])
+    assert np.array_equal(gs.rowptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(ei[1], minlength=n))]))
+    assert np.array_equal(gs.graph_ptr.cpu().numpy(), np.concatenate([[0], np.cumsum(sizes)]))
+    ei_csr = np.stack([ei[0][order], ei[1][order]])
+
+    st = current_stream()
+    dh, du, dpos, dvar = dev(h), dev(u), dev(pos.reshape(-1)), dev(var)
+    msg = torch.empty(e, H, device='cuda')
+    check(L.msmp_edge_mlp_f32(ptr(dh), ptr(du), ptr(dpos), ptr(dvar), ptr(gs.tgt), ptr(gs.col), n, e, tw, nv,
+                              ptr(blob), ptr(msg), st), 'edge')
+    ref_msg = O.edge_messages(p, h64, u64, pos64, var64, ei_csr)
+    err = np.abs(msg.double().cpu().numpy() - ref_msg).max()
+    assert err < 2e-6, f'edge_mlp {err}'
+
+    agg = torch.empty(n, H, device='cuda')
+    check(L.msmp_scatter_mean_f32(ptr(msg), ptr(gs.rowptr), n, ptr(agg), st), 'scatter')
+    ref_agg = O.scatter_mean(msg.double().cpu().numpy(), ei_csr[1], n)
+    err = np.abs(agg.double().cpu().numpy() - ref_agg).max()
+    assert err < 5e-7, f'scatter_mean {err}'
+    deg0 = np.bincount(ei[1], minlength=n) == 0
+    assert not agg.cpu().numpy()[deg0].any()        # nodes without in-edges aggregate to exactly 0
+
+    for mode, lin in ((1, True), (0, False)):
+        out = torch.empty(n, H, device='cuda')
+        check(L.msmp_node_update_f32(ptr(dh), ptr(agg), ptr(dvar), n, nv, ptr(blob), mode, ptr(out), st), 'node')
+        ref = O.node_update(p, h64, agg.double().cpu().numpy(), var64, lin)
+        err = np.abs(out.double().cpu().numpy() - ref).max()
+        assert err < 2e-6, f'node_update mode {mode}: {err}'
+
+    x = dev(rng.standard_normal((n, H)).astype(np.float32) * 0.3 + 1.0)
+    y = torch.empty_like(x)
+    check(L.msmp_instance_norm_f32(ptr(x), ptr(gs.graph_ptr), len(sizes), 1e-5, ptr(y), st), 'norm')
+    ref = O.instance_norm(x.double().cpu().numpy(), batch)
+    err = np.abs(y.double().cpu().numpy() - ref).max()
+    assert err < 5e-6, f'instance_norm {err}'
+
+    g_pre, m_pre = dev(rng.standard_normal((n, H)).astype(np.float32)), dev(rng.standard_normal((n, H)).astype(np.float32))
+    check(L.msmp_gate_blend_f32(ptr(dh), ptr(g_pre), ptr(m_pre), ptr(gs.graph_ptr), len(sizes), 1e-5, ptr(y), st), 'blend')
+    tau = O.sigmoid(O.instance_norm(g_pre.double().cpu().numpy(), batch))
+    ref = (1 - tau) * h64 + tau * O.swish(O.instance_norm(m_pre.double().cpu().numpy(), batch))
+    err = np.abs(y.double().cpu().numpy() - ref).max()
+    assert err < 5e-6, f'gate_blend {err}'
+
+
+@pytest.mark.parametrize('cls,lin', [('GNN_Layer', False), ('GNN_LayerLin', True)])
+def test_mp_layer_golden(mp, cls, lin):
+    """Whole layer against the reference-generated golden vector (pre- and post-norm)."""
+    d = load(f'layer_{cls}.npz')
+    layer = getattr(mp, cls)(H, H, H, 25, 2)
+    layer.load_state_dict({k: torch.tensor(v) for k, v in sd_of(d).items()})
+    layer.cuda()
+    with torch.no_grad():
+        out = layer(dev(d['h']), dev(d['u']), dev(d['pos_x'], torch.float32), dev(d['variables']),
+                    dev(d['edge_index']), dev(d['batch']))
+    err = np.abs(out.double().cpu().numpy() - d['out']).max()
+    assert err < 1e-5, err
+
+
+@pytest.mark.parametrize('exp', ['E2', 'WE3', 'RPU', 'MSWG3'])
+def test_graph_creator_bit_exact(mp, exp):
+    """Rows G1, G2, R1 on the device: edge_index bit-exact (same order), tensors identical to the reference's."""
+    from helpers import EXPERIMENTS
+    d = load(f'graph_{exp}.npz')
+    pde_name, eqv, unstructured = EXPERIMENTS[exp]
+    kw = dict(tmin=float(d['tmin']), tmax=float(d['tmax']), grid_size=[250, 100])
+    pde = {'CE': lambda: mp.CE(L=16., **kw), 'WE': lambda: mp.WE(**kw),
+           'AD': lambda: mp.AD(L=16., unstructured=unstructured, **kw)}[pde_name]()
+    gc = mp.GraphCreator(pde, neighbors=3, time_window=25, device='cuda')
+    u = torch.tensor(d['u_super'].astype(np.float64))
+    steps = d['steps'].tolist()
+    x = torch.tensor(np.tile(d['x_grid'][None], (len(u), 1)))
+    variables = {k[4:]: torch.tensor(v) for k, v in d.items() if k.startswith('var_')}
+    data, labels = gc.create_data(u, steps)
+    g = gc.create_graph(data, labels, x, variables, steps)
+    ref = graph_of(d)
+    assert np.array_equal(g.edge_index.cpu().numpy(), ref.edge_index)
+    for k in ('x', 'y', 'pos', 'batch', 'alpha', 'beta', 'gamma', 'bc_left', 'bc_right', 'c', 'a', 'b'):
+        if hasattr(ref, k):
+            assert np.array_equal(getattr(g, k).cpu().numpy(), getattr(ref, k)), k
+    steps2 = d['steps2'].tolist()
+    _, labels2 = gc.create_data(u, steps2)
+    g2 = gc.create_next_graph(g, torch.tensor(d['pred'].astype(np.float64)).cuda(), labels2, steps2)
+    ref2 = graph_of(d, 'n_')
+    for k in ('x', 'y', 'pos'):
+        assert np.array_equal(getattr(g2, k).cpu().numpy(), getattr(ref2, k)), k
+
+
+def test_graph_builders_random_grids(mp):
+    """radius/knn builders vs the oracle on random ragged 1-D and 2-D point sets (bit-exact)."""
+    rng = np.random.default_rng(5)
+    sizes = [17, 100, 3, 64]
+    batch = np.repeat(np.arange(len(sizes)), sizes)
+    for dim in (1, 2):
+        x = rng.uniform(0, 1, (len(batch), dim))
+        ei = mp.radius_graph(dev(x), 0.11, batch=dev(batch)).cpu().numpy()
+        assert np.array_equal(ei, O.radius_graph(x, 0.11, batch))
+        ei = mp.radius_graph(dev(x), 0.5, batch=dev(batch), max_num_neighbors=4).cpu().numpy()
+        assert np.array_equal(ei, O.radius_graph(x, 0.5, batch, max_num_neighbors=4))
+        for k in (1, 3, 6):
+            ei = mp.knn_graph(dev(x), k, batch=dev(batch)).cpu().numpy()
+            assert np.array_equal(ei, O.knn_graph(x, k, batch))
+    # ties: uniform grid, equal distances left and right -> lower index first
+    x = np.arange(10, dtype=np.float64)
+    ei = mp.knn_graph(dev(x), 2, batch=dev(np.zeros(10, dtype=np.int64))).cpu().numpy()
+    assert np.array_equal(ei, O.knn_graph(x, 2, np.zeros(10, dtype=np.int64)))

@@ -1,0 +1,121 @@
+"""GPU parity tests of the drop-in solver classes (forward + unrolled rollout) against the golden
+vectors produced by the reference's own classes and against the float64 oracle at full depth.
+BASELINE.json bar: float32 node output within 1e-5 of the (float64) CPU reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import msmp_oracle as O
+from helpers import load, sd_of, graph_of, pde_of, EXPERIMENTS, synthetic_case
+
+pytestmark = pytest.mark.gpu
+TW = 25
+TOL = 1e-5      # BASELINE.json north_star: "fp32 node output within 1e-5 of the CPU reference"
+
+
+@pytest.fixture(scope='module')
+def mp():
+    import msmp_pde_amd
+    assert torch.cuda.is_available()
+    msmp_pde_amd.lib()
+    return msmp_pde_amd
+
+
+def make_pde(mp, exp, d):
+    pde_name, eqv, unstructured = EXPERIMENTS[exp]
+    kw = dict(tmin=float(d['tmin']), tmax=float(d['tmax']), grid_size=[250, 100])
+    pde = {'CE': lambda: mp.CE(L=16., **kw), 'WE': lambda: mp.WE(**kw),
+           'AD': lambda: mp.AD(L=16., unstructured=unstructured, **kw)}[pde_name]()
+    return pde, pde_name, eqv
+
+
+def to_data(mp, g):
+    kw = {k: torch.tensor(v) for k, v in vars(g).items()}
+    return mp.Data(**kw).to('cuda')
+
+
+@pytest.mark.parametrize('kind', ['MP_PDE_Solver', 'MP_PDE_SolverGated', 'MP_PDE_Solver2D', 'MP_PDE_Solver2DGated'])
+def test_solver_golden_forward_and_rollout(mp, kind):
+    d = load(f'solver_{kind}.npz')
+    exp = str(d['experiment'])
+    pde, pde_name, eqv = make_pde(mp, exp, d)
+    layers = int(d['hidden_layer'])
+    model = getattr(mp, kind)(pde, time_window=TW, eq_variables=eqv, hidden_layer=layers)
+    # reference state_dict loads by name: key set and shapes must be identical
+    missing = model.load_state_dict({k: torch.tensor(v) for k, v in sd_of(d).items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.cuda().eval()
+    assert repr(model) == 'GNN'
+    g = graph_of(d)
+    data = to_data(mp, g)
+    with torch.no_grad():
+        out = model(data)
+    assert out.dtype == data.x.dtype and out.shape == d['out'].shape
+    err = np.abs(out.double().cpu().numpy() - d['out']).max()
+    print(f'{kind}: max|hip - reference| = {err:.3e}')
+    assert err < TOL, err
+
+    n_roll = int(d['n_roll'])
+    if n_roll:      # experiments/train_helper.py:255-261 through the GraphCreator mirror
+        gc = mp.GraphCreator(pde, neighbors=3, time_window=TW, device='cuda')
+        u = torch.tensor(d['u_super'].astype(np.float64)).cuda()
+        step = 50
+        pred = out
+        for r in range(n_roll):
+            step += TW
+            same = [step] * u.shape[0]
+            _, labels = gc.create_data(u, same)
+            data = gc.create_next_graph(data, pred, labels, same)
+            with torch.no_grad():
+                pred = model(data)
+            err = np.abs(pred.double().cpu().numpy() - d[f'roll{r}']).max()
+            print(f'{kind}: rollout step {r}: {err:.3e}')
+            assert err < TOL, (r, err)
+
+
+@pytest.mark.parametrize('kind,exp', [('MP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'E2'),
+                                      ('MP_PDE_SolverLEMLinGated', 'E2'), ('MP_PDE_SolverGated', 'WE3'),
+                                      ('MP_PDE_Solver2DLEMLinGated', 'RPU'), ('MP_PDE_Solver2DGated', 'MSWG3')])
+def test_full_depth_vs_oracle(mp, kind, exp):
+    """All six classes at the default depth (6 layers / 6 gated pairs) on 8 graphs, default init,
+    against the float64 oracle: the accumulated fp32 error must stay inside the 1e-5 output bar."""
+    torch.manual_seed(3)
+    case = synthetic_case(mp, exp, bsz=8, seed=11)
+    model = getattr(mp, kind)(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=6)
+    model.cuda().eval()
+    data = case.graph.to('cuda')
+    with torch.no_grad():
+        out = model(data)
+        out2 = model(data)
+    assert torch.equal(out, out2)                   # fixed summation order -> bitwise repeatable
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    g = case.graph_np()
+    ref = O.solver_forward(kind, sd, g, case.pde, TW, case.eqv, 6)
+    err = np.abs(out.double().cpu().numpy() - ref).max()
+    print(f'{kind}/{exp}: depth 6, max|hip - oracle| = {err:.3e}')
+    assert err < TOL, err
+
+
+def test_graph_sharding_is_exact(mp):
+    """Multi-GPU row (e): graphs are independent, so evaluating a contiguous shard of the batch gives
+    bit-identical rows to evaluating the whole batch (what each rank does under data parallelism)."""
+    torch.manual_seed(4)
+    case = synthetic_case(mp, 'E2', bsz=6, seed=5)
+    model = mp.MP_PDE_SolverGated(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=2).cuda().eval()
+    with torch.no_grad():
+        full = model(case.graph.to('cuda'))
+    from msmp_pde_amd.dist import shard_graph
+    nx = 100
+    for rank in range(3):
+        sh = shard_graph(case.graph, rank, 3)
+        with torch.no_grad():
+            part = model(sh.to('cuda'))
+        assert torch.equal(part, full[rank * 2 * nx:(rank + 1) * 2 * nx])
+
+
+def test_fails_loudly_without_gpu_tensors(mp):
+    case = synthetic_case(mp, 'E2', bsz=2, seed=1, device='cpu')
+    model = mp.MP_PDE_Solver(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=1)
+    with pytest.raises(Exception):
+        with torch.no_grad():
+            model(case.graph)
