@@ -134,8 +134,8 @@ def test_layer_pieces_vs_oracle(mp, tw, nv, sizes, shuffle):
     check(L.msmp_edge_mlp_f32(ptr(dh), ptr(du), ptr(dpos), ptr(dvar), ptr(gs.tgt), ptr(gs.col), n, e, tw, nv,
                               ptr(blob), ptr(msg), st), 'edge')
     ref_msg = O.edge_messages(p, h64, u64, pos64, var64, ei_csr)
-    err = np.abs(msg.double().cpu().numpy() - ref_msg).max()
-    assert err < 2e-6, f'edge_mlp {err}'
+    err = np.abs(msg.double().cpu().numpy() - ref_msg).max() / max(1.0, np.abs(ref_msg).max())
+    assert err < 1e-6, f'edge_mlp {err}'          # relative to the largest message (inputs here are O(1..10))
 
     agg = torch.empty(n, H, device='cuda')
     check(L.msmp_scatter_mean_f32(ptr(msg), ptr(gs.rowptr), n, ptr(agg), st), 'scatter')
@@ -149,8 +149,8 @@ def test_layer_pieces_vs_oracle(mp, tw, nv, sizes, shuffle):
         out = torch.empty(n, H, device='cuda')
         check(L.msmp_node_update_f32(ptr(dh), ptr(agg), ptr(dvar), n, nv, ptr(blob), mode, ptr(out), st), 'node')
         ref = O.node_update(p, h64, agg.double().cpu().numpy(), var64, lin)
-        err = np.abs(out.double().cpu().numpy() - ref).max()
-        assert err < 2e-6, f'node_update mode {mode}: {err}'
+        err = np.abs(out.double().cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+        assert err < 1e-6, f'node_update mode {mode}: {err}'
 
     x = dev(rng.standard_normal((n, H)).astype(np.float32) * 0.3 + 1.0)
     y = torch.empty_like(x)
