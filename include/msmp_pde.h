@@ -138,6 +138,21 @@ int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const fl
                       float eps, float* h_out, void* workspace, size_t workspace_bytes,
                       msmp_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * In-library kernel timing (measurement aid for bench.py; off by default, not part of the data path)
+ * When enabled, every launch of the named kernel family is bracketed by hipEvents recorded on the
+ * launch stream.  msmp_timing_read synchronises on the recorded events and returns the number of
+ * launches and their summed device time since the last reset.
+ * ------------------------------------------------------------------------------------------- */
+#define MSMP_K_EDGE_MLP     0
+#define MSMP_K_SCATTER_MEAN 1
+#define MSMP_K_NODE_UPDATE  2
+#define MSMP_K_NORM         3   /* instance_norm and gate_blend */
+#define MSMP_K_COUNT        4
+int msmp_timing_enable(int kernel_mask);   /* bit k enables family k; 0 disables all */
+int msmp_timing_reset(void);
+int msmp_timing_read(int kernel, int64_t* launches_out, double* total_ms_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,7 +32,12 @@ SIGNATURES = {
     'msmp_mp_layer_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
     'msmp_mp_layer_f32': (c_int, [c_void_p] * 8 + [c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int,
                                                    c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'msmp_timing_enable': (c_int, [c_int]),
+    'msmp_timing_reset': (c_int, []),
+    'msmp_timing_read': (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
+
+K_EDGE_MLP, K_SCATTER_MEAN, K_NODE_UPDATE, K_NORM = 0, 1, 2, 3
 
 _lib = None
 
@@ -71,3 +76,10 @@ def ptr(t):
 def current_stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def timing_read(kernel):
+    """(launches, total_ms) of one kernel family since the last msmp_timing_reset."""
+    n, ms = c_int64(0), c_double(0.0)
+    check(lib().msmp_timing_read(kernel, ctypes.byref(n), ctypes.byref(ms)), 'msmp_timing_read')
+    return n.value, ms.value

@@ -1,6 +1,7 @@
 // HBM-bound pieces of the message-passing layer: weight packing, mean aggregation (row L2),
 // InstanceNorm (row L4), gate blend (row L5), and the whole-layer entry point that chains the pieces.
 #include <stdarg.h>
+#include <vector>
 #include "msmp_common.h"
 
 namespace msmp {
@@ -21,6 +22,33 @@ int check_launch(const char* what) {
         return MSMP_ERR_HIP;
     }
     return MSMP_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// timing aid (bench.py roofline leg)
+// ----------------------------------------------------------------------------------------------
+struct EventPair {
+    hipEvent_t a, b;
+};
+static int g_timing_mask = 0;
+static std::vector<EventPair> g_events[MSMP_K_COUNT];
+static size_t g_used[MSMP_K_COUNT] = {0, 0, 0, 0};
+
+void timing_begin(int kernel, hipStream_t st) {
+    if (!(g_timing_mask >> kernel & 1)) return;
+    if (g_used[kernel] == g_events[kernel].size()) {
+        EventPair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+        g_events[kernel].push_back(p);
+    }
+    (void)hipEventRecord(g_events[kernel][g_used[kernel]].a, st);
+}
+
+void timing_end(int kernel, hipStream_t st) {
+    if (!(g_timing_mask >> kernel & 1)) return;
+    if (g_used[kernel] >= g_events[kernel].size()) return;
+    (void)hipEventRecord(g_events[kernel][g_used[kernel]].b, st);
+    ++g_used[kernel];
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -165,6 +193,34 @@ __global__ __launch_bounds__(256) void gate_blend_kernel(const float* __restrict
 
 using namespace msmp;
 
+extern "C" int msmp_timing_enable(int kernel_mask) {
+    g_timing_mask = kernel_mask & ((1 << MSMP_K_COUNT) - 1);
+    return MSMP_OK;
+}
+
+extern "C" int msmp_timing_reset(void) {
+    for (int k = 0; k < MSMP_K_COUNT; ++k) g_used[k] = 0;
+    return MSMP_OK;
+}
+
+extern "C" int msmp_timing_read(int kernel, int64_t* launches_out, double* total_ms_out) {
+    MSMP_REQUIRE(kernel >= 0 && kernel < MSMP_K_COUNT && launches_out && total_ms_out, MSMP_ERR_ARG, "msmp_timing_read: bad argument");
+    double tot = 0.0;
+    for (size_t i = 0; i < g_used[kernel]; ++i) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(g_events[kernel][i].b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_events[kernel][i].a, g_events[kernel][i].b);
+        if (e != hipSuccess) {
+            set_error("msmp_timing_read: %s", hipGetErrorString(e));
+            return MSMP_ERR_HIP;
+        }
+        tot += ms;
+    }
+    *launches_out = (int64_t)g_used[kernel];
+    *total_ms_out = tot;
+    return MSMP_OK;
+}
+
 extern "C" int msmp_version(void) { return 100; }
 extern "C" const char* msmp_last_error(void) { return g_err; }
 
@@ -188,7 +244,9 @@ extern "C" int msmp_scatter_mean_f32(const float* msg, const int32_t* rowptr, in
     MSMP_REQUIRE(rowptr && agg_out, MSMP_ERR_ARG, "msmp_scatter_mean_f32: null pointer");
     MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31), MSMP_ERR_ARG, "msmp_scatter_mean_f32: bad n_nodes");
     const unsigned grid = (unsigned)((n_nodes + 7) / 8);
+    timing_begin(MSMP_K_SCATTER_MEAN, (hipStream_t)stream);
     hipLaunchKernelGGL(scatter_mean_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, msg, rowptr, (long)n_nodes, agg_out);
+    timing_end(MSMP_K_SCATTER_MEAN, (hipStream_t)stream);
     return check_launch("scatter_mean_kernel");
 }
 
@@ -196,7 +254,9 @@ extern "C" int msmp_instance_norm_f32(const float* x, const int32_t* graph_ptr, 
                                       msmp_stream_t stream) {
     MSMP_REQUIRE(x && graph_ptr && out, MSMP_ERR_ARG, "msmp_instance_norm_f32: null pointer");
     MSMP_REQUIRE(n_graphs > 0 && n_graphs < (1L << 31), MSMP_ERR_ARG, "msmp_instance_norm_f32: bad n_graphs");
+    timing_begin(MSMP_K_NORM, (hipStream_t)stream);
     hipLaunchKernelGGL(instance_norm_kernel, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, x, graph_ptr, eps, out);
+    timing_end(MSMP_K_NORM, (hipStream_t)stream);
     return check_launch("instance_norm_kernel");
 }
 
@@ -204,8 +264,10 @@ extern "C" int msmp_gate_blend_f32(const float* h, const float* gate_pre, const 
                                    int64_t n_graphs, float eps, float* out, msmp_stream_t stream) {
     MSMP_REQUIRE(h && gate_pre && main_pre && graph_ptr && out, MSMP_ERR_ARG, "msmp_gate_blend_f32: null pointer");
     MSMP_REQUIRE(n_graphs > 0 && n_graphs < (1L << 31), MSMP_ERR_ARG, "msmp_gate_blend_f32: bad n_graphs");
+    timing_begin(MSMP_K_NORM, (hipStream_t)stream);
     hipLaunchKernelGGL(gate_blend_kernel, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, h, gate_pre, main_pre,
                        graph_ptr, eps, out);
+    timing_end(MSMP_K_NORM, (hipStream_t)stream);
     return check_launch("gate_blend_kernel");
 }
 

@@ -350,7 +350,9 @@ extern "C" int msmp_edge_mlp_f32(const float* h, const float* u, const float* po
                packed + L.w1, packed + L.w2, packed + L.b1, packed + L.b2, msg_out};
     constexpr int NB = 2;
     const unsigned grid = (unsigned)((n_edges + 128 * NB - 1) / (128 * NB));
+    timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
     hipLaunchKernelGGL(edge_mlp_kernel<NB>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    timing_end(MSMP_K_EDGE_MLP, (hipStream_t)stream);
     return check_launch("edge_mlp_kernel");
 }
 
@@ -365,6 +367,8 @@ extern "C" int msmp_node_update_f32(const float* h, const float* agg, const floa
                packed + L.b3, packed + L.b4, packed + L.w3v, out};
     constexpr int NB = 1;
     const unsigned grid = (unsigned)((n_nodes + 128 * NB - 1) / (128 * NB));
+    timing_begin(MSMP_K_NODE_UPDATE, (hipStream_t)stream);
     hipLaunchKernelGGL(node_update_kernel<NB>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    timing_end(MSMP_K_NODE_UPDATE, (hipStream_t)stream);
     return check_launch("node_update_kernel");
 }

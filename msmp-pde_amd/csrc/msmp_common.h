@@ -63,6 +63,10 @@ __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 *
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// Optional event bracket around a kernel launch (msmp_timing_*): no-ops unless the family is enabled.
+void timing_begin(int kernel, hipStream_t st);
+void timing_end(int kernel, hipStream_t st);
+
 }  // namespace msmp
 
 #define MSMP_REQUIRE(cond, code, ...)          \

@@ -42,11 +42,22 @@ def linear(x, w, b):
     return x @ w.T + b
 
 
+def _segment_sum(x, index, n):
+    """sum of the rows of x sharing an index -> [n, C] (index_add semantics; rows visited in index order)."""
+    out = np.zeros((n, x.shape[1]), dtype=x.dtype)
+    if len(index) == 0:
+        return out
+    order = np.argsort(index, kind='stable')
+    idx = index[order]
+    starts = np.flatnonzero(np.concatenate(([True], idx[1:] != idx[:-1])))
+    out[idx[starts]] = np.add.reduceat(x[order], starts, axis=0)
+    return out
+
+
 def scatter_mean(msg, target, n):
     """PyG aggr='mean' (experiments/models_gnn.py:42,107): sum over edges sharing a target divided
     by max(in-degree, 1); nodes without in-edges give 0.  Row L2 of SURVEY.md section 8a."""
-    out = np.zeros((n, msg.shape[1]), dtype=msg.dtype)
-    np.add.at(out, target, msg)
+    out = _segment_sum(msg, target, n)
     cnt = np.bincount(target, minlength=n).astype(msg.dtype)
     return out / np.maximum(cnt, 1.0)[:, None]
 
@@ -56,13 +67,9 @@ def instance_norm(x, batch, eps=1e-5):
     per graph and channel (x - mean) / sqrt(biased var + eps).  Row L4."""
     b = int(batch.max()) + 1 if batch.size else 0
     cnt = np.maximum(np.bincount(batch, minlength=b).astype(x.dtype), 1.0)[:, None]
-    mean = np.zeros((b, x.shape[1]), dtype=x.dtype)
-    np.add.at(mean, batch, x)
-    mean /= cnt
+    mean = _segment_sum(x, batch, b) / cnt
     xc = x - mean[batch]
-    var = np.zeros((b, x.shape[1]), dtype=x.dtype)
-    np.add.at(var, batch, xc * xc)
-    var /= cnt
+    var = _segment_sum(xc * xc, batch, b) / cnt
     return xc / np.sqrt(var + eps)[batch]
 
 

@@ -80,6 +80,33 @@ def test_solver_forward_and_rollout(kind):
             assert np.abs(preds[r + 1] - d[f'roll{r}']).max() < 1e-10, r
 
 
+@pytest.mark.parametrize('kind', ['MP_PDE_Solver', 'MP_PDE_SolverGated', 'MP_PDE_Solver2D', 'MP_PDE_Solver2DGated'])
+def test_torch_oracle_matches_golden(kind):
+    """The torch-CPU edition of the oracle (bench.py's cpu_baseline port) against the same golden vectors."""
+    from oracle import msmp_oracle_torch as OT
+    d = load(f'solver_{kind}.npz')
+    _, eqv, _ = EXPERIMENTS[str(d['experiment'])]
+    out = OT.solver_forward(kind, sd_of(d), graph_of(d), pde_of(d), TW, eqv, int(d['hidden_layer']))
+    assert np.abs(out - d['out']).max() < 1e-11
+
+
+def test_torch_oracle_matches_numpy_oracle_lem():
+    """LEM solvers have no golden vector (lem_cuda absent): the two oracle editions must at least agree."""
+    from oracle import msmp_oracle_torch as OT
+    import torch
+    import msmp_pde_amd as mp
+    from helpers import synthetic_case
+    torch.manual_seed(1)
+    for kind, exp in (('MP_PDE_SolverLEMLinGated', 'E2'), ('MP_PDE_Solver2DLEMLinGated', 'RPU')):
+        case = synthetic_case(mp, exp, bsz=2, seed=3, device='cpu')
+        model = getattr(mp, kind)(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=2)
+        sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+        g = case.graph_np()
+        a = O.solver_forward(kind, sd, g, case.pde, TW, case.eqv, 2)
+        b = OT.solver_forward(kind, sd, g, case.pde, TW, case.eqv, 2)
+        assert np.abs(a - b).max() < 1e-10
+
+
 def test_float32_noise_floor_recorded():
     """Context for the 1e-5 bar: the same oracle evaluated in float32 differs from float64 by the
     fp32 noise floor; it must itself be well inside the tolerance the HIP path is held to."""
