@@ -139,6 +139,30 @@ int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const fl
                       msmp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * LEM node encoder (replaces the absent `lem_cuda` extension)
+ * ------------------------------------------------------------------------------------------- */
+/* Pack LEMcuda's parameters (experiments/models_gnn.py:305-330: weights [3*128, 128+ninp], weights_lin_z
+ * [128, 128+ninp], bias [3*128], bias_lin_z [128]; column block 0..127 multiplies the state, the rest
+ * the step input) and optionally lemoutput_mlp.{0,2} (:1287-1291; all four NULL to skip) for
+ * msmp_lem_encoder_f32.  ninp <= 8. */
+int64_t msmp_packed_lem_floats(void);
+int msmp_pack_lem_f32(const float* weights, const float* weights_lin_z, const float* bias,
+                      const float* bias_lin_z, const float* mlp_w0, const float* mlp_b0,
+                      const float* mlp_w1, const float* mlp_b1, int ninp, float* packed_out,
+                      msmp_stream_t stream);
+
+/* Row stride (floats) of the step-input tensor for a given ninp: ninp rounded up to even. */
+int msmp_lem_input_stride(int ninp);
+
+/* LEM.forward (experiments/models_gnn.py:340-342 -> lem_cuda.forward :290) on xin [N, T, stride]
+ * (node-major; row t = the step input torch.cat((pos_x, u_t, variables)) of :1360, zero padded from ninp
+ * to stride = msmp_lem_input_stride(ninp)), zero initial states,
+ * followed when with_mlp != 0 by lemoutput_mlp (:1363).  h_out [N,128] = all_y[-1] (or the MLP of it).
+ * PARITY UNPINNED against lem_cuda (source absent); follows the published LEM cell. */
+int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len, int ninp, float dt,
+                         const float* packed, int with_mlp, float* h_out, msmp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * In-library kernel timing (measurement aid for bench.py; off by default, not part of the data path)
  * When enabled, every launch of the named kernel family is bracketed by hipEvents recorded on the
  * launch stream.  msmp_timing_read synchronises on the recorded events and returns the number of
@@ -148,7 +172,8 @@ int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const fl
 #define MSMP_K_SCATTER_MEAN 1
 #define MSMP_K_NODE_UPDATE  2
 #define MSMP_K_NORM         3   /* instance_norm and gate_blend */
-#define MSMP_K_COUNT        4
+#define MSMP_K_LEM          4
+#define MSMP_K_COUNT        5
 int msmp_timing_enable(int kernel_mask);   /* bit k enables family k; 0 disables all */
 int msmp_timing_reset(void);
 int msmp_timing_read(int kernel, int64_t* launches_out, double* total_ms_out);

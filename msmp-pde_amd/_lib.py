@@ -32,12 +32,16 @@ SIGNATURES = {
     'msmp_mp_layer_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
     'msmp_mp_layer_f32': (c_int, [c_void_p] * 8 + [c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int,
                                                    c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'msmp_packed_lem_floats': (c_int64, []),
+    'msmp_pack_lem_f32': (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p]),
+    'msmp_lem_input_stride': (c_int, [c_int]),
+    'msmp_lem_encoder_f32': (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     'msmp_timing_enable': (c_int, [c_int]),
     'msmp_timing_reset': (c_int, []),
     'msmp_timing_read': (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
 
-K_EDGE_MLP, K_SCATTER_MEAN, K_NODE_UPDATE, K_NORM = 0, 1, 2, 3
+K_EDGE_MLP, K_SCATTER_MEAN, K_NODE_UPDATE, K_NORM, K_LEM = 0, 1, 2, 3, 4
 
 _lib = None
 

@@ -15,74 +15,9 @@
 //     one barrier per chunk; the packed blob stores chunks contiguously so staging is a flat copy.
 // k order inside a chunk is k = 8q + 4hh + m (q, m = 0..3): one 16-byte fragment load covers four
 // MFMA steps for both operands.  fp32 MFMA is an exact k-ordered fmaf chain (no reduced precision).
-#include "msmp_common.h"
+#include "mfma_tiles.h"
 
 namespace msmp {
-
-struct WStage {
-    f32x4 r[4];
-};
-
-__device__ __forceinline__ void wstage_load(WStage& s, const float* __restrict__ chunk, int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s.r[i] = *reinterpret_cast<const f32x4*>(chunk + 4 * (tid + 256 * i));
-}
-
-__device__ __forceinline__ void wstage_store(const WStage& s, float* buf, int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i;
-        *reinterpret_cast<f32x4*>(buf + (idx >> 3) * LDW + (idx & 7) * 4) = s.r[i];
-    }
-}
-
-// acc[T][nb] += W_chunk[32T.., k] * B[k][item]  for the 32 k of one staged chunk.
-template <int NB>
-__device__ __forceinline__ void mma_chunk(const float* wl, int c, int hh, const f32x4 (&b)[NB][4],
-                                          f32x16 (&acc)[4][NB]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 a[4];
-#pragma unroll
-        for (int T = 0; T < 4; ++T)
-            a[T] = *reinterpret_cast<const f32x4*>(wl + (32 * T + c) * LDW + 8 * q + 4 * hh);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int T = 0; T < 4; ++T)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[T][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[T][m], b[nb][q][m], acc[T][nb], 0, 0, 0);
-    }
-}
-
-// Same, with the B operand taken from the accumulators of the previous GEMM (tile t = chunk index).
-template <int NB>
-__device__ __forceinline__ void mma_chunk_from_acc(const float* wl, int c, int hh, const f32x16 (&x)[NB],
-                                                   f32x16 (&acc)[4][NB]) {
-    f32x4 b[NB][4];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) b[nb][q][m] = x[nb][4 * q + m];
-    mma_chunk<NB>(wl, c, hh, b, acc);
-}
-
-template <int NB>
-__device__ __forceinline__ void acc_init_bias(const float* __restrict__ bias, int hh, f32x16 (&acc)[4][NB]) {
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * T + 8 * q + 4 * hh);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[T][nb][4 * q + m] = bv[m];
-        }
-}
 
 // ----------------------------------------------------------------------------------------------
 // L1: edge messages

@@ -14,6 +14,8 @@ import math
 import torch
 from torch import nn
 
+from ._lib import lib, check, ptr, current_stream
+
 
 class LEMcuda(nn.Module):
     """Parameter holder named like the reference's (experiments/models_gnn.py:305-330)."""
@@ -53,12 +55,47 @@ class LEMcuda(nn.Module):
 
 
 class LEM(nn.Module):
-    """experiments/models_gnn.py:333-342: returns all_y[-1]."""
+    """experiments/models_gnn.py:333-342: returns all_y[-1].
+
+    `forward` is the PyTorch restatement (differentiable; used when autograd is on).  `encode` is the
+    product path for inference: the fused HIP kernel msmp_lem_encoder_f32 (recurrence + lemoutput_mlp in
+    one launch, states in registers)."""
 
     def __init__(self, ninp, nhid, dt=1.):
         super().__init__()
         self.ninp, self.nhid = ninp, nhid
         self.rnn = LEMcuda(ninp, nhid, dt)
+        self._packed = None
+        self._packed_key = None
 
     def forward(self, inputs):
         return self.rnn(inputs)
+
+    def _pack(self, mlp):
+        ps = [self.rnn.weights, self.rnn.weights_lin_z, self.rnn.bias, self.rnn.bias_lin_z]
+        if mlp is not None:
+            ps += [mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias]
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        if key != self._packed_key:
+            L = lib()
+            blob = torch.empty(L.msmp_packed_lem_floats(), dtype=torch.float32, device=ps[0].device)
+            f = [p.detach().to(torch.float32).contiguous() for p in ps]
+            args = [ptr(t) for t in f] + [None] * (8 - len(f))
+            check(L.msmp_pack_lem_f32(*args, self.ninp, ptr(blob), current_stream()), 'msmp_pack_lem_f32')
+            self._packed, self._packed_key = blob, key
+        return self._packed
+
+    def encode(self, xin, mlp=None):
+        """xin [N, T, ninp] float32 CUDA (node-major step inputs) -> [N, nhid]; `mlp` = lemoutput_mlp
+        (nn.Sequential(Linear, Swish, Linear, Swish)) to fuse behind the recurrence."""
+        assert self.nhid == 128 and xin.shape[2] == self.ninp
+        L = lib()
+        n, t_len, _ = xin.shape
+        stride = L.msmp_lem_input_stride(self.ninp)
+        if stride != self.ninp:
+            xin = torch.nn.functional.pad(xin, (0, stride - self.ninp))
+        xin = xin.to(torch.float32).contiguous()
+        out = torch.empty(n, self.nhid, dtype=torch.float32, device=xin.device)
+        check(L.msmp_lem_encoder_f32(ptr(xin), n, t_len, self.ninp, self.rnn.dt, ptr(self._pack(mlp)),
+                                     int(mlp is not None), ptr(out), current_stream()), 'msmp_lem_encoder_f32')
+        return out

@@ -105,8 +105,10 @@ class _SolverBase(nn.Module):
             t_len = u.shape[1]
             lem_in = torch.cat((pos_x[:, None, :].expand(n, t_len, 1), u[:, :, None],
                                 variables[:, None, :].expand(n, t_len, variables.shape[1])), -1)
-        h = self.embedding_lem(lem_in.permute(1, 0, 2).contiguous())
-        return self.lemoutput_mlp(h)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.embedding_lem.parameters()):
+            h = self.embedding_lem(lem_in.permute(1, 0, 2).contiguous())     # differentiable PyTorch restatement
+            return self.lemoutput_mlp(h)
+        return self.embedding_lem.encode(lem_in, self.lemoutput_mlp)       # fused HIP kernel (recurrence + MLP)
 
     # -- forward -------------------------------------------------------------------------------
     def forward(self, data):

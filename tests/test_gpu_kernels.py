@@ -228,3 +228,27 @@ def test_graph_builders_random_grids(mp):
     x = np.arange(10, dtype=np.float64)
     ei = mp.knn_graph(dev(x), 2, batch=dev(np.zeros(10, dtype=np.int64))).cpu().numpy()
     assert np.array_equal(ei, O.knn_graph(x, 2, np.zeros(10, dtype=np.int64)))
+
+
+@pytest.mark.parametrize('ninp,t_len,n', [(4, 25, 300), (5, 25, 129), (6, 25, 64), (3, 7, 1000), (8, 50, 33)])
+def test_lem_encoder_kernel(mp, ninp, t_len, n):
+    """Fused LEM encoder (recurrence + lemoutput_mlp) vs the float64 oracle cell.  PARITY UNPINNED against
+    lem_cuda (absent from the reference); this pins the kernel to the restated cell only."""
+    torch.manual_seed(ninp)
+    lem = mp.LEM(ninp, 128).cuda()
+    mlp = torch.nn.Sequential(torch.nn.Linear(128, 128), mp.Swish(), torch.nn.Linear(128, 128), mp.Swish()).cuda()
+    xin = torch.randn(n, t_len, ninp, device='cuda')
+    with torch.no_grad():
+        y = lem.encode(xin, None)
+        h = lem.encode(xin, mlp)
+        y_torch = lem(xin.permute(1, 0, 2).contiguous())
+    sd = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in lem.state_dict().items()}
+    ref_y = O.lem_forward(xin.permute(1, 0, 2).double().cpu().numpy(), sd['rnn.weights'], sd['rnn.weights_lin_z'],
+                          sd['rnn.bias'], sd['rnn.bias_lin_z'], 1.0)
+    w = [p.detach().double().cpu().numpy() for p in (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)]
+    ref_h = O.swish(O.linear(O.swish(O.linear(ref_y, w[0], w[1])), w[2], w[3]))
+    e_y = np.abs(y.double().cpu().numpy() - ref_y).max()
+    e_h = np.abs(h.double().cpu().numpy() - ref_h).max()
+    e_t = np.abs(y_torch.double().cpu().numpy() - ref_y).max()
+    print(f'lem ninp={ninp} T={t_len}: hip y {e_y:.2e}, hip h {e_h:.2e}, torch-gpu y {e_t:.2e}')
+    assert e_y < 5e-6 and e_h < 5e-6
