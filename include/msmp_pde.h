@@ -105,6 +105,15 @@ int msmp_edge_mlp_f32(const float* h, const float* u, const float* pos, const fl
                       const int32_t* tgt, const int32_t* col, int64_t n_nodes, int64_t n_edges,
                       int tw, int nv, const float* packed, float* msg_out, msmp_stream_t stream);
 
+/* L1 + L2 fused: agg[i] = mean over the in-edges of i of the message above, without materialising the
+ * [E,128] message tensor (messages are reduced per target inside the workgroup, in CSR order).  Needs
+ * every target's in-edges to fit one workgroup tile: max_in_degree <= 256, else MSMP_ERR_UNSUPPORTED
+ * (then use msmp_edge_mlp_f32 + msmp_scatter_mean_f32). */
+int msmp_edge_aggregate_f32(const float* h, const float* u, const float* pos, const float* vars,
+                            const int32_t* rowptr, const int32_t* col, const int32_t* tgt,
+                            int64_t n_nodes, int64_t n_edges, int max_in_degree, int tw, int nv,
+                            const float* packed, float* agg_out, msmp_stream_t stream);
+
 /* L2  PyG aggr='mean' (torch_scatter scatter-mean; experiments/models_gnn.py:42,107):
  *   agg[i] = sum_{e in CSR row i} msg[e] / max(deg_i, 1), fixed summation order (CSR order). */
 int msmp_scatter_mean_f32(const float* msg, const int32_t* rowptr, int64_t n_nodes,
@@ -129,12 +138,15 @@ int msmp_gate_blend_f32(const float* h, const float* gate_pre, const float* main
 /* One whole message-passing layer: GNN_Layer.forward / GNN_LayerLin.forward
  * (experiments/models_gnn.py:61-67 / 124-130) = L1 -> L2 -> L3 -> L4; when packed_gate != NULL the
  * gated pair of one iteration of the solver loop (L5) is evaluated and blended.  h_out may not alias h.
- * Workspace size from msmp_mp_layer_workspace_bytes. */
-size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges, int gated);
+ * max_in_degree = largest CSR row length (pass -1 if unknown): when <= 256 the fused L1+L2 kernel is
+ * used, otherwise the message tensor goes through the workspace.  Workspace size from
+ * msmp_mp_layer_workspace_bytes (same max_in_degree). */
+size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges, int gated, int max_in_degree);
 int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars,
                       const int32_t* rowptr, const int32_t* col, const int32_t* tgt,
                       const int32_t* graph_ptr, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
-                      int tw, int nv, const float* packed_main, const float* packed_gate, int mode,
+                      int max_in_degree, int tw, int nv, const float* packed_main,
+                      const float* packed_gate, int mode,
                       float eps, float* h_out, void* workspace, size_t workspace_bytes,
                       msmp_stream_t stream);
 

@@ -271,18 +271,20 @@ extern "C" int msmp_gate_blend_f32(const float* h, const float* gate_pre, const 
     return check_launch("gate_blend_kernel");
 }
 
-// Workspace of the chained layer: msg [E,128] | agg [N,128] | pre_main [N,128] | pre_gate [N,128] (gated only)
+// Workspace of the chained layer: [msg [E,128] unless the fused edge kernel applies] | agg [N,128] |
+// pre_main [N,128] | pre_gate [N,128] (gated only)
 static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+static bool fused_ok(int max_in_degree) { return max_in_degree >= 0 && max_in_degree <= 256; }
 
-extern "C" size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges, int gated) {
-    const size_t msg = align256((size_t)n_edges * H * sizeof(float));
+extern "C" size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges, int gated, int max_in_degree) {
+    const size_t msg = fused_ok(max_in_degree) ? 0 : align256((size_t)n_edges * H * sizeof(float));
     const size_t nod = align256((size_t)n_nodes * H * sizeof(float));
-    return msg + nod * (gated ? 3 : 2);
+    return msg + nod * (gated ? 3 : 2) + 256;
 }
 
 extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars,
                                  const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const int32_t* graph_ptr,
-                                 int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int tw, int nv,
+                                 int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int max_in_degree, int tw, int nv,
                                  const float* packed_main, const float* packed_gate, int mode, float eps, float* h_out,
                                  void* workspace, size_t workspace_bytes, msmp_stream_t stream) {
     MSMP_REQUIRE(h && u && pos && vars && rowptr && col && tgt && graph_ptr && packed_main && h_out && workspace,
@@ -290,23 +292,30 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
     MSMP_REQUIRE(h_out != h, MSMP_ERR_ARG, "msmp_mp_layer_f32: h_out may not alias h");
     const int gated = packed_gate != nullptr;
     MSMP_REQUIRE(!gated || mode == MSMP_LAYER_LIN, MSMP_ERR_ARG, "msmp_mp_layer_f32: the gated pair uses GNN_LayerLin layers");
-    MSMP_REQUIRE(workspace_bytes >= msmp_mp_layer_workspace_bytes(n_nodes, n_edges, gated), MSMP_ERR_WORKSPACE,
-                 "msmp_mp_layer_f32: workspace %zu < %zu", workspace_bytes, msmp_mp_layer_workspace_bytes(n_nodes, n_edges, gated));
+    const size_t need = msmp_mp_layer_workspace_bytes(n_nodes, n_edges, gated, max_in_degree);
+    MSMP_REQUIRE(workspace_bytes >= need, MSMP_ERR_WORKSPACE, "msmp_mp_layer_f32: workspace %zu < %zu", workspace_bytes, need);
+    const bool fused = fused_ok(max_in_degree);
     char* ws = (char*)workspace;
     float* msg = (float*)ws;
-    ws += align256((size_t)n_edges * H * sizeof(float));
+    if (!fused) ws += align256((size_t)n_edges * H * sizeof(float));
     const size_t nod = align256((size_t)n_nodes * H * sizeof(float));
     float* agg = (float*)ws;
     float* pre_main = (float*)(ws + nod);
     float* pre_gate = (float*)(ws + 2 * nod);
     int rc;
+    // message + mean (rows L1 + L2): one fused launch when every target's in-edges fit a workgroup tile
+    auto aggregate = [&](const float* packed) -> int {
+        if (fused)
+            return msmp_edge_aggregate_f32(h, u, pos, vars, rowptr, col, tgt, n_nodes, n_edges, max_in_degree, tw, nv, packed,
+                                           agg, stream);
+        const int r = msmp_edge_mlp_f32(h, u, pos, vars, tgt, col, n_nodes, n_edges, tw, nv, packed, msg, stream);
+        return r ? r : msmp_scatter_mean_f32(msg, rowptr, n_nodes, agg, stream);
+    };
     if (gated) {
-        if ((rc = msmp_edge_mlp_f32(h, u, pos, vars, tgt, col, n_nodes, n_edges, tw, nv, packed_gate, msg, stream))) return rc;
-        if ((rc = msmp_scatter_mean_f32(msg, rowptr, n_nodes, agg, stream))) return rc;
+        if ((rc = aggregate(packed_gate))) return rc;
         if ((rc = msmp_node_update_f32(h, agg, vars, n_nodes, nv, packed_gate, MSMP_LAYER_LIN, pre_gate, stream))) return rc;
     }
-    if ((rc = msmp_edge_mlp_f32(h, u, pos, vars, tgt, col, n_nodes, n_edges, tw, nv, packed_main, msg, stream))) return rc;
-    if ((rc = msmp_scatter_mean_f32(msg, rowptr, n_nodes, agg, stream))) return rc;
+    if ((rc = aggregate(packed_main))) return rc;
     if ((rc = msmp_node_update_f32(h, agg, vars, n_nodes, nv, packed_main, mode, pre_main, stream))) return rc;
     if (gated) return msmp_gate_blend_f32(h, pre_gate, pre_main, graph_ptr, n_graphs, eps, h_out, stream);
     return msmp_instance_norm_f32(pre_main, graph_ptr, n_graphs, eps, h_out, stream);

@@ -29,13 +29,16 @@ struct EdgeArgs {
     const float* vars;
     const int* tgt;
     const int* col;
-    long n_edges;
+    const int* rowptr;   // FUSE only
+    long n_edges, n_nodes;
+    int tile_nodes;      // FUSE only: nodes per workgroup tile (tile_nodes * max in-degree <= 128*NB)
     int tw, nv, nc1;
     const float* w1;   // nc1 chunks
     const float* w2;   // 4 chunks
     const float* b1;
     const float* b2;
-    float* msg;
+    float* msg;          // !FUSE: [E,128] messages
+    float* agg;          // FUSE:  [N,128] mean of the messages of each target
 };
 
 // B fragments of chunk `c` of the concatenated edge feature [h_i | h_j | u_i-u_j | p_i-p_j | v_i | 0...]
@@ -62,19 +65,35 @@ __device__ __forceinline__ void edge_gather(const EdgeArgs& a, int c, int i, int
     }
 }
 
-template <int NB>
+// FUSE = false: one workgroup per 128*NB consecutive CSR edges, writes msg [E,128] (row L1 alone).
+// FUSE = true : one workgroup per tile of `tile_nodes` consecutive target nodes (all their in-edges, at
+//               most 128*NB); after GEMM2 the messages are staged through LDS one 32-channel tile at a
+//               time (re-using the weight buffers) and reduced per target in CSR order -> agg [N,128]
+//               (rows L1 + L2): the [E,128] message tensor never touches HBM.
+template <int NB, bool FUSE>
 __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
-    const long e0 = (long)blockIdx.x * (128 * NB) + (long)wave * (32 * NB);
+    long tile_e0, tile_e1;     // CSR edge range of this workgroup
+    int tile_n0 = 0, tile_n1 = 0;
+    if (FUSE) {
+        tile_n0 = blockIdx.x * a.tile_nodes;
+        tile_n1 = min((long)tile_n0 + a.tile_nodes, a.n_nodes);
+        tile_e0 = a.rowptr[tile_n0];
+        tile_e1 = a.rowptr[tile_n1];
+    } else {
+        tile_e0 = (long)blockIdx.x * (128 * NB);
+        tile_e1 = min(tile_e0 + 128 * NB, a.n_edges);
+    }
+    const long e0 = tile_e0 + (long)wave * (32 * NB);
 
     long e[NB];
     int ni[NB], nj[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         e[nb] = e0 + 32 * nb + c;
-        const long ec = e[nb] < a.n_edges ? e[nb] : a.n_edges - 1;
+        const long ec = e[nb] < tile_e1 ? e[nb] : a.n_edges - 1;
         ni[nb] = a.tgt[ec];
         nj[nb] = a.col[ec];
     }
@@ -127,20 +146,50 @@ __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeArgs a) {
         }
     }
 
-    // msg[e][32T + 8q + 4hh + m] = Swish(y)
+    if (!FUSE) {
+        // msg[e][32T + 8q + 4hh + m] = Swish(y)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        if (e[nb] < a.n_edges) {
-            float* o = a.msg + (size_t)e[nb] * H + 4 * hh;
+        for (int nb = 0; nb < NB; ++nb) {
+            if (e[nb] < tile_e1) {
+                float* o = a.msg + (size_t)e[nb] * H + 4 * hh;
 #pragma unroll
-            for (int T = 0; T < 4; ++T)
+                for (int T = 0; T < 4; ++T)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) v[m] = swishf(y[T][nb][4 * q + m]);
+                        *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = v;
+                    }
+            }
+        }
+    } else {
+        // Mean over the in-edges of each target, one 32-channel tile at a time:
+        // stage [128*NB local edges][32 ch] (row stride LDW) in the weight buffers, then thread
+        // (slot = tid >> 3, cq = tid & 7) sums the rows of node tile_n0 + slot (+32, ...) for channels 4cq..4cq+3.
+        const int cq = tid & 7, slot = tid >> 3;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            __syncthreads();     // previous readers of lds (W2 chunk 3 / previous tile) are done
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float* o = lds + (wave * 32 * NB + 32 * nb + c) * LDW + 4 * hh;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 v;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) v[m] = swishf(y[T][nb][4 * q + m]);
-                    *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = v;
+                    *reinterpret_cast<f32x4*>(o + 8 * q) = v;
                 }
+            }
+            __syncthreads();
+            for (int node = tile_n0 + slot; node < tile_n1; node += 32) {
+                const int r0 = a.rowptr[node] - (int)tile_e0, r1 = a.rowptr[node + 1] - (int)tile_e0;
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                for (int r = r0; r < r1; ++r) sum += *reinterpret_cast<const f32x4*>(lds + r * LDW + 4 * cq);
+                const float inv = 1.0f / (float)max(r1 - r0, 1);
+                *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + 32 * T + 4 * cq) = sum * inv;
+            }
         }
     }
 }
@@ -281,14 +330,42 @@ extern "C" int msmp_edge_mlp_f32(const float* h, const float* u, const float* po
     MSMP_REQUIRE(n_edges < (1L << 31) && n_nodes < (1L << 31), MSMP_ERR_UNSUPPORTED, "msmp_edge_mlp_f32: int32 index range");
     if (n_edges == 0) return MSMP_OK;
     const PackedLayout L = packed_layout(tw, nv);
-    EdgeArgs a{h, u, pos, vars, tgt, col, (long)n_edges, tw, nv, L.nc1,
-               packed + L.w1, packed + L.w2, packed + L.b1, packed + L.b2, msg_out};
+    EdgeArgs a{h, u, pos, vars, tgt, col, nullptr, (long)n_edges, (long)n_nodes, 0, tw, nv, L.nc1,
+               packed + L.w1, packed + L.w2, packed + L.b1, packed + L.b2, msg_out, nullptr};
     constexpr int NB = 2;
     const unsigned grid = (unsigned)((n_edges + 128 * NB - 1) / (128 * NB));
     timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
-    hipLaunchKernelGGL(edge_mlp_kernel<NB>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((edge_mlp_kernel<NB, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     timing_end(MSMP_K_EDGE_MLP, (hipStream_t)stream);
     return check_launch("edge_mlp_kernel");
+}
+
+extern "C" int msmp_edge_aggregate_f32(const float* h, const float* u, const float* pos, const float* vars,
+                                       const int32_t* rowptr, const int32_t* col, const int32_t* tgt, int64_t n_nodes,
+                                       int64_t n_edges, int max_in_degree, int tw, int nv, const float* packed,
+                                       float* agg_out, msmp_stream_t stream) {
+    MSMP_REQUIRE(h && u && pos && vars && rowptr && col && tgt && packed && agg_out, MSMP_ERR_ARG, "msmp_edge_aggregate_f32: null pointer");
+    MSMP_REQUIRE(n_nodes > 0 && n_edges >= 0 && tw > 0 && nv >= 1 && nv <= MSMP_MAX_VARS && max_in_degree >= 0, MSMP_ERR_ARG,
+                 "msmp_edge_aggregate_f32: bad sizes");
+    MSMP_REQUIRE(n_edges < (1L << 31) && n_nodes < (1L << 31), MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_f32: int32 index range");
+    if (n_edges == 0) {     // every node has an empty neighbourhood: the mean is 0
+        const hipError_t me = hipMemsetAsync(agg_out, 0, (size_t)n_nodes * H * sizeof(float), (hipStream_t)stream);
+        MSMP_REQUIRE(me == hipSuccess, MSMP_ERR_HIP, "msmp_edge_aggregate_f32: memset: %s", hipGetErrorString(me));
+        return MSMP_OK;
+    }
+    constexpr int NB = 2;
+    MSMP_REQUIRE(max_in_degree <= 128 * NB, MSMP_ERR_UNSUPPORTED,
+                 "msmp_edge_aggregate_f32: max in-degree %d > %d (use msmp_edge_mlp_f32 + msmp_scatter_mean_f32)", max_in_degree, 128 * NB);
+    const PackedLayout L = packed_layout(tw, nv);
+    int tile_nodes = max_in_degree > 0 ? (128 * NB) / max_in_degree : 128 * NB;
+    if (tile_nodes > 256) tile_nodes = 256;      // keeps the per-tile node loop short when degrees are tiny
+    EdgeArgs a{h, u, pos, vars, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, tw, nv, L.nc1,
+               packed + L.w1, packed + L.w2, packed + L.b1, packed + L.b2, nullptr, agg_out};
+    const unsigned grid = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
+    timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
+    hipLaunchKernelGGL((edge_mlp_kernel<NB, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    timing_end(MSMP_K_EDGE_MLP, (hipStream_t)stream);
+    return check_launch("edge_mlp_kernel<fused mean>");
 }
 
 extern "C" int msmp_node_update_f32(const float* h, const float* agg, const float* vars, int64_t n_nodes, int nv,

@@ -62,6 +62,8 @@ class GraphStructure(object):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         check(L.msmp_build_csr(ptr(ei), self.n_edges, self.n_nodes, ptr(self.rowptr), ptr(self.col), ptr(self.tgt),
                                ptr(ws), ws_bytes, current_stream()), 'msmp_build_csr')
+        # largest in-degree decides whether the fused message+mean kernel applies (one D2H read per structure)
+        self.max_in_degree = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if self.n_edges else 0
         self._key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
                      batch.data_ptr(), batch._version)
 

@@ -124,10 +124,10 @@ def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5):
     assert variables.shape[1] == main.n_variables and pos_x.numel() == n
     out = torch.empty_like(h)
     gated = gate is not None
-    ws_bytes = L.msmp_mp_layer_workspace_bytes(n, gs.n_edges, int(gated))
+    ws_bytes = L.msmp_mp_layer_workspace_bytes(n, gs.n_edges, int(gated), gs.max_in_degree)
     ws = _Workspace.get(ws_bytes, h.device)
     check(L.msmp_mp_layer_f32(ptr(h), ptr(u), ptr(pos_x), ptr(variables), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt),
-                              ptr(gs.graph_ptr), n, gs.n_edges, gs.n_graphs, main.time_window, main.n_variables,
+                              ptr(gs.graph_ptr), n, gs.n_edges, gs.n_graphs, gs.max_in_degree, main.time_window, main.n_variables,
                               ptr(main.packed()), ptr(gate.packed()) if gated else None, main.MODE, eps, ptr(out),
                               ptr(ws), ws.numel(), current_stream()), 'msmp_mp_layer_f32')
     return out

@@ -145,6 +145,12 @@ def test_layer_pieces_vs_oracle(mp, tw, nv, sizes, shuffle):
     deg0 = np.bincount(ei[1], minlength=n) == 0
     assert not agg.cpu().numpy()[deg0].any()        # nodes without in-edges aggregate to exactly 0
 
+    # fused L1+L2 (no [E,128] tensor in HBM): same per-target summation order -> bit-identical to the two kernels
+    agg_f = torch.full((n, H), float('nan'), device='cuda')
+    check(L.msmp_edge_aggregate_f32(ptr(dh), ptr(du), ptr(dpos), ptr(dvar), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt), n, e,
+                                    gs.max_in_degree, tw, nv, ptr(blob), ptr(agg_f), st), 'edge_aggregate')
+    assert torch.equal(agg_f, agg)
+
     for mode, lin in ((1, True), (0, False)):
         out = torch.empty(n, H, device='cuda')
         check(L.msmp_node_update_f32(ptr(dh), ptr(agg), ptr(dvar), n, nv, ptr(blob), mode, ptr(out), st), 'node')
@@ -252,3 +258,36 @@ def test_lem_encoder_kernel(mp, ninp, t_len, n):
     e_t = np.abs(y_torch.double().cpu().numpy() - ref_y).max()
     print(f'lem ninp={ninp} T={t_len}: hip y {e_y:.2e}, hip h {e_h:.2e}, torch-gpu y {e_t:.2e}')
     assert e_y < 5e-6 and e_h < 5e-6
+
+
+def test_fused_aggregate_degree_limits(mp):
+    """Hub nodes: in-degree up to 256 runs fused; above that the fused entry point refuses (and
+    msmp_mp_layer_f32 takes the message-tensor path), both matching the oracle."""
+    from msmp_pde_amd._lib import ptr, current_stream
+    from msmp_pde_amd.graph import GraphStructure
+    L = mp.lib()
+    rng = np.random.default_rng(7)
+    tw, nv, n = 25, 2, 400
+    for hub_deg in (256, 300):
+        src = list(rng.choice(np.arange(1, n), size=hub_deg, replace=False))        # hub = node 0
+        dst = [0] * hub_deg
+        for i in range(1, n):
+            js = rng.choice([j for j in range(n) if j != i], size=3, replace=False)
+            src += js.tolist(); dst += [i] * 3
+        ei = np.array([src, dst], dtype=np.int64)
+        batch = np.zeros(n, dtype=np.int64)
+        h, u, pos, var = layer_inputs(rng, n, tw, nv)
+        layer = mp.GNN_LayerLin(H, H, H, tw, nv).cuda()
+        gs = GraphStructure(dev(ei), dev(batch), n)
+        assert gs.max_in_degree == hub_deg
+        with torch.no_grad():
+            out = mp.mp_layer(dev(h), dev(u), dev(pos), dev(var), gs, layer)
+        sd = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+        ref = O.mp_layer(O.layer_params(sd, ''), h.astype(np.float64), u.astype(np.float64), pos.astype(np.float64),
+                         var.astype(np.float64), ei, batch, True)
+        assert np.abs(out.double().cpu().numpy() - ref).max() < 2e-5
+        agg = torch.empty(n, H, device='cuda')
+        rc = L.msmp_edge_aggregate_f32(ptr(dev(h)), ptr(dev(u)), ptr(dev(pos.reshape(-1))), ptr(dev(var)), ptr(gs.rowptr), ptr(gs.col),
+                                       ptr(gs.tgt), n, ei.shape[1], gs.max_in_degree, tw, nv, ptr(layer.packed()), ptr(agg),
+                                       current_stream())
+        assert rc == (0 if hub_deg <= 256 else -2)
