@@ -127,7 +127,7 @@ def main():
         pred = model(graph)
         for i in range(args.warmup):
             pred = rollout_step(i, pred)
-        mask = 0b11111 if args.time_all_kernels else 0b00001
+        mask = 0b111111 if args.time_all_kernels else 0b000001
         L.msmp_timing_reset()
         L.msmp_timing_enable(mask)
         D.barrier()
@@ -175,7 +175,7 @@ def main():
     }
     if args.time_all_kernels:
         names = {_lib.K_SCATTER_MEAN: 'scatter_mean', _lib.K_NODE_UPDATE: 'node_update', _lib.K_NORM: 'norm_blend',
-                 _lib.K_LEM: 'lem_encoder'}
+                 _lib.K_LEM: 'lem_encoder', _lib.K_NODE_PROJ: 'node_project'}
         out['kernels_ms_per_step'] = {'edge_mlp': ms_total / args.steps}
         for k, nm in names.items():
             n_k, ms_k = _lib.timing_read(k)

@@ -39,11 +39,17 @@ extern "C" {
 /* flags for msmp_node_update_f32 / msmp_mp_layer_f32 */
 #define MSMP_LAYER_RESIDUAL_SWISH 0  /* GNN_Layer.update    experiments/models_gnn.py:77-86  : x + Swish(W4 . + b4) */
 #define MSMP_LAYER_LIN            1  /* GNN_LayerLin.update experiments/models_gnn.py:140-149: W4 . + b4           */
+/* OR-ed into `mode` of msmp_mp_layer_f32: evaluate message_net_1 on the materialised per-edge
+ * concatenation (the reference's literal order of operations) instead of the per-node factorisation. */
+#define MSMP_LAYER_DENSE_MESSAGE  16
 
 typedef void* msmp_stream_t;
 
 int msmp_version(void);
 const char* msmp_last_error(void);
+/* Tuning knobs for A/B measurements (not part of the data contract). key "edge_nb": 0 auto, 1 / 2 force the
+ * 128- / 256-edge tile of the factorised message kernel. */
+int msmp_tune(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * Weights
@@ -113,6 +119,20 @@ int msmp_edge_aggregate_f32(const float* h, const float* u, const float* pos, co
                             const int32_t* rowptr, const int32_t* col, const int32_t* tgt,
                             int64_t n_nodes, int64_t n_edges, int max_in_degree, int tw, int nv,
                             const float* packed, float* agg_out, msmp_stream_t stream);
+
+/* Per-node factorisation of message_net_1 (linear in its concatenated input):
+ *   W1 [h_i, h_j, u_i-u_j, p_i-p_j, v_i] + b1 = P[i] + Q[j],
+ *   P[n] = W1[:, 0:128] h_n + W1[:, 256:] [u_n, p_n, v_n] + b1,   Q[n] = W1[:, 128:256] h_n - W1[:, 256:] [u_n, p_n, 0].
+ * msmp_node_project_f32 writes P and Q [N,128]; msmp_edge_aggregate_projected_f32 then computes the same
+ * agg as msmp_edge_aggregate_f32 from them (5.3x fewer FLOPs in message_net_1; only the place where partial
+ * sums are rounded differs).  This is the default inside msmp_mp_layer_f32. */
+int msmp_node_project_f32(const float* h, const float* u, const float* pos, const float* vars,
+                          int64_t n_nodes, int tw, int nv, const float* packed, float* p_out,
+                          float* q_out, msmp_stream_t stream);
+int msmp_edge_aggregate_projected_f32(const float* p, const float* q, const int32_t* rowptr,
+                                      const int32_t* col, const int32_t* tgt, int64_t n_nodes,
+                                      int64_t n_edges, int max_in_degree, int tw, int nv,
+                                      const float* packed, float* agg_out, msmp_stream_t stream);
 
 /* L2  PyG aggr='mean' (torch_scatter scatter-mean; experiments/models_gnn.py:42,107):
  *   agg[i] = sum_{e in CSR row i} msg[e] / max(deg_i, 1), fixed summation order (CSR order). */
@@ -185,7 +205,8 @@ int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len, int ninp,
 #define MSMP_K_NODE_UPDATE  2
 #define MSMP_K_NORM         3   /* instance_norm and gate_blend */
 #define MSMP_K_LEM          4
-#define MSMP_K_COUNT        5
+#define MSMP_K_NODE_PROJ    5
+#define MSMP_K_COUNT        6
 int msmp_timing_enable(int kernel_mask);   /* bit k enables family k; 0 disables all */
 int msmp_timing_reset(void);
 int msmp_timing_read(int kernel, int64_t* launches_out, double* total_ms_out);

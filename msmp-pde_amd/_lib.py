@@ -16,6 +16,7 @@ HIDDEN = 128
 SIGNATURES = {
     'msmp_version': (c_int, []),
     'msmp_last_error': (c_char_p, []),
+    'msmp_tune': (c_int, [c_char_p, c_int]),
     'msmp_packed_layer_floats': (c_int64, [c_int, c_int]),
     'msmp_pack_layer_f32': (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p, c_void_p]),
     'msmp_build_csr_workspace_bytes': (c_size_t, [c_int64, c_int64]),
@@ -30,6 +31,8 @@ SIGNATURES = {
     'msmp_instance_norm_f32': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     'msmp_gate_blend_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     'msmp_edge_aggregate_f32': (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'msmp_node_project_f32': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'msmp_edge_aggregate_projected_f32': (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'msmp_mp_layer_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int, c_int]),
     'msmp_mp_layer_f32': (c_int, [c_void_p] * 8 + [c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                                    c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -42,7 +45,8 @@ SIGNATURES = {
     'msmp_timing_read': (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
 
-K_EDGE_MLP, K_SCATTER_MEAN, K_NODE_UPDATE, K_NORM, K_LEM = 0, 1, 2, 3, 4
+K_EDGE_MLP, K_SCATTER_MEAN, K_NODE_UPDATE, K_NORM, K_LEM, K_NODE_PROJ = 0, 1, 2, 3, 4, 5
+MSMP_LAYER_DENSE_MESSAGE = 16
 
 _lib = None
 

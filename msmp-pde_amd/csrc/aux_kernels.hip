@@ -32,7 +32,7 @@ struct EventPair {
 };
 static int g_timing_mask = 0;
 static std::vector<EventPair> g_events[MSMP_K_COUNT];
-static size_t g_used[MSMP_K_COUNT] = {0, 0, 0, 0, 0};
+static size_t g_used[MSMP_K_COUNT] = {0, 0, 0, 0, 0, 0};
 
 void timing_begin(int kernel, hipStream_t st) {
     if (!(g_timing_mask >> kernel & 1)) return;
@@ -272,14 +272,15 @@ extern "C" int msmp_gate_blend_f32(const float* h, const float* gate_pre, const 
 }
 
 // Workspace of the chained layer: [msg [E,128] unless the fused edge kernel applies] | agg [N,128] |
-// pre_main [N,128] | pre_gate [N,128] (gated only)
+// pre_main [N,128] | pre_gate [N,128] | P [N,128] | Q [N,128]
 static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 static bool fused_ok(int max_in_degree) { return max_in_degree >= 0 && max_in_degree <= 256; }
 
 extern "C" size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges, int gated, int max_in_degree) {
     const size_t msg = fused_ok(max_in_degree) ? 0 : align256((size_t)n_edges * H * sizeof(float));
     const size_t nod = align256((size_t)n_nodes * H * sizeof(float));
-    return msg + nod * (gated ? 3 : 2) + 256;
+    (void)gated;
+    return msg + nod * 5 + 256;
 }
 
 extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars,
@@ -291,6 +292,8 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
                  MSMP_ERR_ARG, "msmp_mp_layer_f32: null pointer");
     MSMP_REQUIRE(h_out != h, MSMP_ERR_ARG, "msmp_mp_layer_f32: h_out may not alias h");
     const int gated = packed_gate != nullptr;
+    const bool dense = (mode & MSMP_LAYER_DENSE_MESSAGE) != 0;
+    mode &= ~MSMP_LAYER_DENSE_MESSAGE;
     MSMP_REQUIRE(!gated || mode == MSMP_LAYER_LIN, MSMP_ERR_ARG, "msmp_mp_layer_f32: the gated pair uses GNN_LayerLin layers");
     const size_t need = msmp_mp_layer_workspace_bytes(n_nodes, n_edges, gated, max_in_degree);
     MSMP_REQUIRE(workspace_bytes >= need, MSMP_ERR_WORKSPACE, "msmp_mp_layer_f32: workspace %zu < %zu", workspace_bytes, need);
@@ -302,9 +305,16 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
     float* agg = (float*)ws;
     float* pre_main = (float*)(ws + nod);
     float* pre_gate = (float*)(ws + 2 * nod);
+    float* pbuf = (float*)(ws + 3 * nod);
+    float* qbuf = (float*)(ws + 4 * nod);
     int rc;
     // message + mean (rows L1 + L2): one fused launch when every target's in-edges fit a workgroup tile
     auto aggregate = [&](const float* packed) -> int {
+        if (fused && !dense) {
+            const int r = msmp_node_project_f32(h, u, pos, vars, n_nodes, tw, nv, packed, pbuf, qbuf, stream);
+            return r ? r : msmp_edge_aggregate_projected_f32(pbuf, qbuf, rowptr, col, tgt, n_nodes, n_edges, max_in_degree, tw,
+                                                              nv, packed, agg, stream);
+        }
         if (fused)
             return msmp_edge_aggregate_f32(h, u, pos, vars, rowptr, col, tgt, n_nodes, n_edges, max_in_degree, tw, nv, packed,
                                            agg, stream);

