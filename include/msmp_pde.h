@@ -195,6 +195,16 @@ int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len, int ninp,
                          const float* packed, int with_mlp, float* h_out, msmp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Decoder
+ * ------------------------------------------------------------------------------------------- */
+/* 1-D solver decoder, experiments/models_gnn.py:210-224 (output_mlp for time_window 20 / 25 / 50) and
+ * :275-279:  out = u[:, -1:] + cumsum(dt) * Conv1d(8,1,k2)(Swish(Conv1d(1,8,k1,stride)(h[:, None, :]))).
+ * w1 [8,1,k1], b1 [8], w2 [1,8,k2], b2 [1] in the reference's Conv1d layouts; h [N,128]; u, out [N,tw]. */
+int msmp_decoder_f32(const float* h, const float* u, int64_t n_nodes, int tw, const float* w1,
+                     const float* b1, const float* w2, const float* b2, float dt, float* out,
+                     msmp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * In-library kernel timing (measurement aid for bench.py; off by default, not part of the data path)
  * When enabled, every launch of the named kernel family is bracketed by hipEvents recorded on the
  * launch stream.  msmp_timing_read synchronises on the recorded events and returns the number of
@@ -206,7 +216,8 @@ int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len, int ninp,
 #define MSMP_K_NORM         3   /* instance_norm and gate_blend */
 #define MSMP_K_LEM          4
 #define MSMP_K_NODE_PROJ    5
-#define MSMP_K_COUNT        6
+#define MSMP_K_DECODER      6
+#define MSMP_K_COUNT        7
 int msmp_timing_enable(int kernel_mask);   /* bit k enables family k; 0 disables all */
 int msmp_timing_reset(void);
 int msmp_timing_read(int kernel, int64_t* launches_out, double* total_ms_out);

@@ -40,12 +40,13 @@ SIGNATURES = {
     'msmp_pack_lem_f32': (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p]),
     'msmp_lem_input_stride': (c_int, [c_int]),
     'msmp_lem_encoder_f32': (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
+    'msmp_decoder_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     'msmp_timing_enable': (c_int, [c_int]),
     'msmp_timing_reset': (c_int, []),
     'msmp_timing_read': (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
 }
 
-K_EDGE_MLP, K_SCATTER_MEAN, K_NODE_UPDATE, K_NORM, K_LEM, K_NODE_PROJ = 0, 1, 2, 3, 4, 5
+K_EDGE_MLP, K_SCATTER_MEAN, K_NODE_UPDATE, K_NORM, K_LEM, K_NODE_PROJ, K_DECODER = 0, 1, 2, 3, 4, 5, 6
 MSMP_LAYER_DENSE_MESSAGE = 16
 
 _lib = None

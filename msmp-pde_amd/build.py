@@ -13,6 +13,7 @@ SOURCES = {  # file -> extra flags
     'mlp_kernels.hip': [],
     'aux_kernels.hip': [],
     'lem_kernel.hip': [],
+    'decoder_kernel.hip': [],
     'graph_kernels.hip': ['-ffp-contract=off'],   # float64 distance compares must round like the host's
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',

@@ -32,7 +32,7 @@ struct EventPair {
 };
 static int g_timing_mask = 0;
 static std::vector<EventPair> g_events[MSMP_K_COUNT];
-static size_t g_used[MSMP_K_COUNT] = {0, 0, 0, 0, 0, 0};
+static size_t g_used[MSMP_K_COUNT] = {};
 
 void timing_begin(int kernel, hipStream_t st) {
     if (!(g_timing_mask >> kernel & 1)) return;

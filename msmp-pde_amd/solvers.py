@@ -17,6 +17,7 @@ the dtype of `data.x`.
 import torch
 from torch import nn
 
+from ._lib import lib, check, ptr, current_stream
 from .graph import structure_of
 from .layers import GNN_Layer, GNN_LayerLin, Swish, mp_layer
 from .lem import LEM
@@ -131,9 +132,16 @@ class _SolverBase(nn.Module):
         if self.TWO_D:                  # models_gnn2D.py:125-141
             diff = self.output_mlp(self.double_mlp(h))
             out = (u.view(-1, 2, tw) + dt.view(1, 1, tw) * diff).flatten(1, 2)
-        else:                           # models_gnn.py:275-279
-            diff = self.output_mlp(h[:, None]).squeeze(1)
+        elif torch.is_grad_enabled() and any(p.requires_grad for p in self.output_mlp.parameters()):
+            diff = self.output_mlp(h[:, None]).squeeze(1)          # differentiable PyTorch decoder
             out = u[:, -1:] + dt.view(1, tw) * diff
+        else:                           # models_gnn.py:275-279, fused: conv -> Swish -> conv -> u + cumsum(dt) * diff
+            out = torch.empty_like(u)
+            c1, c2 = self.output_mlp[0], self.output_mlp[2]
+            w = [p.detach().to(torch.float32).contiguous() for p in (c1.weight, c1.bias, c2.weight, c2.bias)]   # kept alive
+            h = h.contiguous()
+            check(lib().msmp_decoder_f32(ptr(h), ptr(u), u.shape[0], tw, ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[3]),
+                                         float(self.pde.dt), ptr(out), current_stream()), 'msmp_decoder_f32')
         return out.to(u_in.dtype)
 
 

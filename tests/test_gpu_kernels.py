@@ -306,7 +306,31 @@ def test_fused_aggregate_degree_limits(mp):
                          var.astype(np.float64), ei, batch, True)
         assert np.abs(out.double().cpu().numpy() - ref).max() < 2e-5
         agg = torch.empty(n, H, device='cuda')
-        rc = L.msmp_edge_aggregate_f32(ptr(dev(h)), ptr(dev(u)), ptr(dev(pos.reshape(-1))), ptr(dev(var)), ptr(gs.rowptr), ptr(gs.col),
+        th, tu, tp, tv = dev(h), dev(u), dev(pos.reshape(-1)), dev(var)
+        rc = L.msmp_edge_aggregate_f32(ptr(th), ptr(tu), ptr(tp), ptr(tv), ptr(gs.rowptr), ptr(gs.col),
                                        ptr(gs.tgt), n, ei.shape[1], gs.max_in_degree, tw, nv, ptr(layer.packed()), ptr(agg),
                                        current_stream())
         assert rc == (0 if hub_deg <= 256 else -2)
+
+
+@pytest.mark.parametrize('tw', [20, 25, 50])
+def test_decoder_kernel(mp, tw):
+    """Fused 1-D decoder (conv -> Swish -> conv -> u_last + cumsum(dt) * diff) vs the oracle's conv1d restatement."""
+    from msmp_pde_amd._lib import check, ptr, current_stream
+    rng = np.random.default_rng(tw)
+    k1, s1, k2 = O._DECODER[tw]
+    n = 1000
+    h = rng.standard_normal((n, H)).astype(np.float32)
+    u = rng.standard_normal((n, tw)).astype(np.float32)
+    w1 = (rng.uniform(-1, 1, (8, 1, k1)) / np.sqrt(k1)).astype(np.float32); b1 = rng.uniform(-.2, .2, 8).astype(np.float32)
+    w2 = (rng.uniform(-1, 1, (1, 8, k2)) / np.sqrt(8 * k2)).astype(np.float32); b2 = rng.uniform(-.2, .2, 1).astype(np.float32)
+    dt = 4.0 / 249
+    out = torch.empty(n, tw, device='cuda')
+    t = [dev(a) for a in (h, u, w1, b1, w2, b2)]       # keep the device tensors alive across the call
+    check(mp.lib().msmp_decoder_f32(ptr(t[0]), ptr(t[1]), n, tw, ptr(t[2]), ptr(t[3]), ptr(t[4]), ptr(t[5]), dt,
+                                    ptr(out), current_stream()), 'decoder')
+    f = lambda a: a.astype(np.float64)
+    diff = O.conv1d(O.swish(O.conv1d(f(h)[:, None, :], f(w1), f(b1), s1)), f(w2), f(b2), 1)[:, 0, :]
+    ref = f(u)[:, -1:] + np.cumsum(np.ones(tw) * dt)[None, :] * diff
+    err = np.abs(out.double().cpu().numpy() - ref).max()
+    assert err < 1e-6, err
