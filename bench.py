@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-graphs', type=int, default=128)
     ap.add_argument('--cpu-sample-steps', type=int, default=3)
+    ap.add_argument('--dist-backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo lets two ranks share one GPU for testing')
     ap.add_argument('--time-all-kernels', action='store_true', help='event-time every kernel family, not only the dominant one')
     return ap.parse_args()
 
@@ -96,7 +97,8 @@ def main():
     from msmp_pde_amd import dist as D, _lib
     from msmp_pde_amd.synthetic import make_case, EXPERIMENTS
 
-    rank, world, local = D.init_from_env()
+    rank, world, local = D.init_from_env(args.dist_backend)
+    local = local % max(torch.cuda.device_count(), 1)      # (testing) more ranks than GPUs: share devices
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback)'
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local)
