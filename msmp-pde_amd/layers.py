@@ -113,19 +113,10 @@ def _f32c(t):
 DENSE_MESSAGE = False     # True: evaluate message_net_1 on the per-edge concatenation (reference order of operations)
 
 
-def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense_message=None):
-    """One message-passing layer (or one gated pair) on the device through msmp_mp_layer_f32.
-    h [N,128], u [N,Tw], pos_x [N,1] or [N], variables [N,nv]: float32 CUDA tensors.
-    dense_message: None -> module default (factorised message_net_1); True -> literal per-edge GEMM."""
-    if torch.is_grad_enabled() and any(p.requires_grad for p in main.parameters()):
-        raise NotImplementedError('backward kernels are not built yet (DESIGN.md, "next" rows): run the HIP '
-                                  'message-passing path under torch.no_grad()')
+def _mp_layer_hip(h, u, pos_x, variables, gs, main, gate, eps, dense_message=None):
+    """The HIP call proper (no autograd): msmp_mp_layer_f32."""
     L = lib()
-    gs = structure
-    h, u, pos_x, variables = _f32c(h), _f32c(u), _f32c(pos_x).reshape(-1), _f32c(variables)
     n = h.shape[0]
-    assert n == gs.n_nodes and h.shape[1] == HIDDEN and u.shape[1] == main.time_window
-    assert variables.shape[1] == main.n_variables and pos_x.numel() == n
     out = torch.empty_like(h)
     gated = gate is not None
     dense = DENSE_MESSAGE if dense_message is None else dense_message
@@ -137,3 +128,25 @@ def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense
                               ptr(main.packed()), ptr(gate.packed()) if gated else None, mode, eps, ptr(out),
                               ptr(ws), ws.numel(), current_stream()), 'msmp_mp_layer_f32')
     return out
+
+
+def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense_message=None):
+    """One message-passing layer (or one gated pair) on the device through msmp_mp_layer_f32.
+    h [N,128], u [N,Tw], pos_x [N,1] or [N], variables [N,nv]: float32 CUDA tensors.
+    dense_message: None -> module default (factorised message_net_1); True -> literal per-edge GEMM.
+    Under autograd (training) the forward is the same HIP call and the backward is a PyTorch-ROCm recompute
+    (msmp_pde_amd.autograd; dedicated backward kernels are a later row)."""
+    gs = structure
+    if gs is None or h.device.type != 'cuda':
+        raise _lib.MsmpError('mp_layer needs CUDA tensors and a GraphStructure (HIP path only, no CPU fallback)')
+    need_grad = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in main.parameters()))
+    hd, u, pos_x, variables = _f32c(h), _f32c(u), _f32c(pos_x).reshape(-1), _f32c(variables)
+    n = hd.shape[0]
+    assert n == gs.n_nodes and hd.shape[1] == HIDDEN and u.shape[1] == main.time_window
+    assert variables.shape[1] == main.n_variables and pos_x.numel() == n
+    if not need_grad:
+        return _mp_layer_hip(hd, u, pos_x, variables, gs, main, gate, eps, dense_message)
+    from .autograd import MPLayerFunction
+    params = list(main._params8()) + (list(gate._params8()) if gate is not None else [])
+    hin = h if (h.dtype == torch.float32 and h.is_contiguous()) else h.to(torch.float32).contiguous()
+    return MPLayerFunction.apply(hin, u, pos_x, variables, gs, main, gate, eps, _mp_layer_hip, *params)

@@ -58,9 +58,11 @@ def lem_forward(inputs, w, wz, bias, bz, dt=1.0):
     return y
 
 
-def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=6):
-    """forward(data) of the six in-scope solver classes (see msmp_oracle.solver_forward for the line map)."""
-    t64 = lambda a: torch.as_tensor(a).to(torch.float64)
+def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=6, as_numpy=True):
+    """forward(data) of the six in-scope solver classes (see msmp_oracle.solver_forward for the line map).
+    `sd` values may be float64 torch tensors that require grad (as_numpy=False keeps the autograd graph:
+    used to check the product's gradients)."""
+    t64 = lambda a: a.to(torch.float64) if torch.is_tensor(a) else torch.as_tensor(a).to(torch.float64)
     sd = {k: t64(v) for k, v in sd.items()}
     tw = time_window
     two_d = kind in O.KINDS_2D
@@ -100,4 +102,4 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
         diff = F.conv1d(swish(F.conv1d(h[:, None, :], sd['output_mlp.0.weight'], sd['output_mlp.0.bias'], stride=s1)),
                         sd['output_mlp.2.weight'], sd['output_mlp.2.bias'])[:, 0, :]
         out = u[:, -1:] + dt[None, :] * diff
-    return out.numpy()
+    return out.detach().numpy() if as_numpy else out

@@ -115,7 +115,7 @@ def test_no_cpu_fallback(mp):
     model = mp.MP_PDE_Solver(case.pde, time_window=25, eq_variables=case.eqv, hidden_layer=1)
     with torch.no_grad(), pytest.raises(mp.MsmpError):
         model(case.graph)
-    with pytest.raises(NotImplementedError):     # training backward: not built yet, and says so
+    with pytest.raises(mp.MsmpError):            # no structure / host tensors: refused, also under autograd
         layer = model.gnn_layers[0]
         mp.mp_layer(torch.zeros(2, 128), torch.zeros(2, 25), torch.zeros(2, 1), torch.zeros(2, 2), None, layer)
 
