@@ -2,7 +2,7 @@
 // InstanceNorm (row L4), gate blend (row L5), and the whole-layer entry point that chains the pieces.
 #include <stdarg.h>
 #include <vector>
-#include "msmp_common.h"
+#include "mfma_tiles.h"
 
 namespace msmp {
 
@@ -64,7 +64,7 @@ __global__ void pack_layer_kernel(PackArgs a) {
     const PackedLayout L = packed_layout(a.tw, a.nv);
     const int k1 = 2 * H + a.tw + 1 + a.nv;   // in-features of message_net_1
     const int k3 = 2 * H + a.nv;              // in-features of update_net_1
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < L.total; p += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < L.w3s; p += (int64_t)gridDim.x * blockDim.x) {
         float v = 0.f;
         if (p < L.w4) {                       // w3 chunks
             const int64_t o = p - L.w3;
@@ -93,6 +93,61 @@ __global__ void pack_layer_kernel(PackArgs a) {
             v = a.w2[(size_t)row * H + ch * KC + kk];
         }
         a.out[p] = v;
+    }
+}
+
+// Power-of-two scale of each weight matrix for the fp16-split copies: max|w| * 2^s in [16, 32).
+// grid = 4 (one block per matrix); writes scales[i] = 2^s, scales[4 + i] = 2^-s.
+__global__ __launch_bounds__(256) void pack_layer_scale_kernel(PackArgs a) {
+    __shared__ float red[256];
+    const PackedLayout L = packed_layout(a.tw, a.nv);
+    const int k1 = 2 * H + a.tw + 1 + a.nv, k3 = 2 * H + a.nv;
+    const float* w = blockIdx.x == 0 ? a.w1 : blockIdx.x == 1 ? a.w2 : blockIdx.x == 2 ? a.w3 : a.w4;
+    const int n = H * (blockIdx.x == 0 ? k1 : blockIdx.x == 2 ? k3 : H);
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mx = red[0];
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);          // mx = f * 2^e, f in [0.5, 1)
+        const int sft = mx > 0.f ? 5 - e : 0;                        // mx * 2^sft in [16, 32)
+        a.out[L.scales + blockIdx.x] = ldexpf(1.0f, sft);
+        a.out[L.scales + 4 + blockIdx.x] = ldexpf(1.0f, -sft);
+    }
+}
+
+// fp16-split copies of the four weight matrices (mfma_tiles.h): element index within a 8192-half chunk is
+// (((s*4 + T)*2 + plane)*64 + lane)*8 + j; values are W * 2^s split into hi + lo.
+__global__ void pack_layer_split_kernel(PackArgs a) {
+    const PackedLayout L = packed_layout(a.tw, a.nv);
+    const int k1 = 2 * H + a.tw + 1 + a.nv, k3 = 2 * H + a.nv;
+    _Float16* out = reinterpret_cast<_Float16*>(a.out + L.w3s);
+    const float* sc = a.out + L.scales;
+    const int64_t n_half = (L.scales - L.w3s) * 2;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_half; p += (int64_t)gridDim.x * blockDim.x) {
+        int ch = (int)(p >> 13);
+        const int idx = (int)(p & 8191);
+        const int j = idx & 7, lane = (idx >> 3) & 63, plane = (idx >> 9) & 1, T = (idx >> 10) & 3, s = (idx >> 12) & 1;
+        const int row = 32 * T + (lane & 31), h = lane >> 5;
+        float w;
+        if (ch < 8) {                                   // w3s: natural order over [h | agg] columns
+            w = a.w3[(size_t)row * k3 + 32 * ch + split_k_natural(s, h, j)] * sc[2];
+        } else if (ch < 12) {                           // w4s: acc order
+            w = a.w4[(size_t)row * H + 32 * (ch - 8) + split_k_acc(s, h, j)] * sc[3];
+        } else if (ch < 12 + L.nc1) {                   // w1s: natural order, zero padded past k1
+            const int k = 32 * (ch - 12) + split_k_natural(s, h, j);
+            w = k < k1 ? a.w1[(size_t)row * k1 + k] * sc[0] : 0.f;
+        } else {                                        // w2s: acc order
+            w = a.w2[(size_t)row * H + 32 * (ch - 12 - L.nc1) + split_k_acc(s, h, j)] * sc[1];
+        }
+        const _Float16 hi = (_Float16)w;
+        out[p] = plane == 0 ? hi : (_Float16)(w - (float)hi);
     }
 }
 
@@ -236,6 +291,8 @@ extern "C" int msmp_pack_layer_f32(const float* w1, const float* b1, const float
     MSMP_REQUIRE(tw > 0 && nv >= 1 && nv <= MSMP_MAX_VARS, MSMP_ERR_ARG, "msmp_pack_layer_f32: bad tw=%d nv=%d", tw, nv);
     PackArgs a{w1, b1, w2, b2, w3, b3, w4, b4, tw, nv, packed_out};
     hipLaunchKernelGGL(pack_layer_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(pack_layer_scale_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(pack_layer_split_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("pack_layer_kernel");
 }
 

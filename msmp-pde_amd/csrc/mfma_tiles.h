@@ -77,4 +77,94 @@ __device__ __forceinline__ void acc_init_bias(const float* __restrict__ bias, in
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// fp32 GEMM on the fp16 matrix pipe ("2-way fp16 split"), 5.3x fewer matrix-pipe cycles than
+// v_mfma_f32_32x32x2_f32 at fp32-class accuracy:
+//   x = hi + lo,  hi = fp16_rne(x),  lo = fp16_rne(x - hi)          (|x - hi - lo| <= 2^-24 |x| while lo is normal)
+//   a.b = hi_a hi_b + hi_a lo_b + lo_a hi_b + O(2^-24 |a b|)
+// Three v_mfma_f32_32x32x16_f16 per K = 16 step into ONE fp32 accumulator.  fp16 products are exact in the
+// fp32 accumulation and a K = 128 dot product is 24 accumulation steps instead of 64, so the result is at
+// least as accurate as the fp32 MFMA chain (measured in tests/test_gpu_kernels.py: 2.3-3.1e-7 vs 4.0-6.6e-7).
+// Range: the low part of a small number falls into the fp16 subnormals (quantum 6e-8).  For activations
+// (O(1) values) that is an absolute error <= 3e-8, below fp32's own at that magnitude.  Weights are small
+// (~0.05), so every weight matrix is pre-multiplied by a power of two 2^s chosen by the pack kernel such that
+// max|w| 2^s is in [16, 32) (exact; low parts of all significant weights stay normal); accumulators are
+// initialised with bias * 2^s and the result is multiplied by 2^-s (both exact).
+// Weights are pre-split by the pack kernels into "split chunks" of 16 KB:
+//   [s 2][T 4][plane 2][lane 64][8 halfs]   (one ds_read_b128 = one A fragment, lane-linear: conflict-free)
+// covering [128 out][32 k]; element j of lane (r, h) is W[32T + r][k] with
+//   natural order  k = 16s + 8h + j                        (B gathered from memory, 8 consecutive k per lane)
+//   acc order      k = 16s + 8(j >> 2) + 4h + (j & 3)      (B taken from a 32x32 accumulator: registers 8s..8s+7)
+// ------------------------------------------------------------------------------------------------
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr int SPLIT_CHUNK_FLOATS = 4096;      // 16 KB, same footprint as an fp32 chunk
+
+__device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)x[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(x[j] - (float)h);
+    }
+}
+
+__device__ __forceinline__ void wstage_store_linear(const WStage& s, float* buf, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(buf + 4 * (tid + 256 * i)) = s.r[i];
+}
+
+// acc += W_chunk * B  for the 32 k of one split chunk; bhi/blo[nb][s] are the B fragments of the two K=16 steps.
+template <int NB>
+__device__ __forceinline__ void mma_chunk_split(const float* wl, int lane, const half8 (&bhi)[NB][2], const half8 (&blo)[NB][2],
+                                                f32x16 (&acc)[4][NB]) {
+    const half8* w = reinterpret_cast<const half8*>(wl) + lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            const half8 ahi = w[((s * 4 + T) * 2 + 0) * 64];
+            const half8 alo = w[((s * 4 + T) * 2 + 1) * 64];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                acc[T][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[nb][s], acc[T][nb], 0, 0, 0);
+                acc[T][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[nb][s], acc[T][nb], 0, 0, 0);
+                acc[T][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[nb][s], acc[T][nb], 0, 0, 0);
+            }
+        }
+}
+
+// B fragments of one accumulator tile (acc order): step s takes registers 8s..8s+7.
+template <int NB>
+__device__ __forceinline__ void split_acc_tile(const f32x16 (&x)[NB], half8 (&bhi)[NB][2], half8 (&blo)[NB][2]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = x[nb][8 * s + j];
+            split8(v, bhi[nb][s], blo[nb][s]);
+        }
+}
+
+// acc[T][nb][r] = bias[row] * scale   (accumulator initialisation of a split GEMM whose weights carry 2^s)
+template <int NB>
+__device__ __forceinline__ void acc_init_bias_scaled(const float* __restrict__ bias, float scale, int hh, f32x16 (&acc)[4][NB]) {
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * T + 8 * q + 4 * hh);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[T][nb][4 * q + m] = bv[m] * scale;
+        }
+}
+
+// Host/device: value of element (s, T, plane, lane, j) of a split chunk built from W[row][k0 + k] (row stride ld).
+__host__ __device__ inline int split_k_natural(int s, int h, int j) { return 16 * s + 8 * h + j; }
+__host__ __device__ inline int split_k_acc(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
 }  // namespace msmp

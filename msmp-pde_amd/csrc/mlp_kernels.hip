@@ -36,6 +36,8 @@ struct EdgeArgs {
     int tw, nv, nc1;
     const float* w1;   // nc1 chunks
     const float* w2;   // 4 chunks
+    const float* w2s;  // 4 split chunks (acc order)
+    const float* scales;  // [8] 2^s, 2^-s of w1..w4
     const float* b1;
     const float* b2;
     const float* P;      // FACT: [N,128] target-side projection  W1[:, h_i|u|p|v] . + b1   (node_proj_kernel)
@@ -78,9 +80,11 @@ __device__ __forceinline__ void edge_gather(const EdgeArgs& a, int c, int i, int
 //               GEMM1 disappears from the edge kernel, Swish(P_i + Q_j) is formed straight in the B-operand
 //               registers of GEMM2.  Rounding differs from the dense form only in where the partial sums
 //               are rounded (validated against the float64 oracle with the same bars).
-template <int NB, bool FUSE, bool FACT>
-__global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
+// SPLIT (with FACT): message_net_2 on the fp16 matrix pipe with the 2-way fp16 split of mfma_tiles.h (fp32-class
+//               accuracy, 5.3x fewer matrix-pipe cycles); weights from the split chunks `w2s` of the blob.
+template <int NB, bool FUSE, bool FACT, bool SPLIT>
+__device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
+    static_assert(!SPLIT || FACT, "the split path is built for the factorised kernel");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     long tile_e0, tile_e1;     // CSR edge range of this workgroup
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeArgs a) {
     WStage ws;
     int par;                     // LDS buffer holding W2 chunk 0
     if (FACT) {
-        wstage_load(ws, a.w2, tid);
+        wstage_load(ws, SPLIT ? a.w2s : a.w2, tid);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const float* pp = a.P + (size_t)ni[nb] * H + 4 * hh;
@@ -125,7 +129,8 @@ __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeArgs a) {
                     for (int m = 0; m < 4; ++m) z[T][nb][4 * q + m] = swishf(pv[m] + qv[m]);
                 }
         }
-        wstage_store(ws, lds, tid);
+        if (SPLIT) wstage_store_linear(ws, lds, tid);
+        else wstage_store(ws, lds, tid);
         __syncthreads();
         par = 0;
     } else {
@@ -164,14 +169,36 @@ __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeArgs a) {
     }
 
     f32x16 y[4][NB];
-    acc_init_bias<NB>(a.b2, hh, y);
+    if (SPLIT) {
+        acc_init_bias_scaled<NB>(a.b2, a.scales[1], hh, y);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        if (t < 3) wstage_load(ws, a.w2 + (size_t)(t + 1) * CHUNK_FLOATS, tid);
-        mma_chunk_from_acc<NB>(lds + ((par + t) & 1) * H * LDW, c, hh, z[t], y);
-        if (t < 3) {
-            wstage_store(ws, lds + ((par + t + 1) & 1) * H * LDW, tid);
-            __syncthreads();
+        for (int t = 0; t < 4; ++t) {
+            if (t < 3) wstage_load(ws, a.w2s + (size_t)(t + 1) * SPLIT_CHUNK_FLOATS, tid);
+            half8 bhi[NB][2], blo[NB][2];
+            split_acc_tile<NB>(z[t], bhi, blo);
+            mma_chunk_split<NB>(lds + (t & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, y);
+            if (t < 3) {
+                wstage_store_linear(ws, lds + ((t + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+                __syncthreads();
+            }
+        }
+        const float inv2 = a.scales[5];
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[T][nb][r] *= inv2;
+    } else {
+        acc_init_bias<NB>(a.b2, hh, y);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < 3) wstage_load(ws, a.w2 + (size_t)(t + 1) * CHUNK_FLOATS, tid);
+            mma_chunk_from_acc<NB>(lds + ((par + t) & 1) * H * LDW, c, hh, z[t], y);
+            if (t < 3) {
+                wstage_store(ws, lds + ((par + t + 1) & 1) * H * LDW, tid);
+                __syncthreads();
+            }
         }
     }
 
@@ -221,6 +248,20 @@ __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeArgs a) {
             }
         }
     }
+}
+
+template <int NB, bool FUSE, bool FACT, bool SPLIT = false>
+__global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
+    edge_mlp_body<NB, FUSE, FACT, SPLIT>(a, lds);
+}
+
+// Same body held to <= 256 registers so that two workgroups share a CU (one's gathers / Swish / reduce overlap the
+// other's matrix work).
+template <int NB, bool FUSE, bool FACT, bool SPLIT = false>
+__global__ __launch_bounds__(256, 2) void edge_mlp_kernel_occ2(EdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
+    edge_mlp_body<NB, FUSE, FACT, SPLIT>(a, lds);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -447,7 +488,7 @@ extern "C" int msmp_edge_mlp_f32(const float* h, const float* u, const float* po
     if (n_edges == 0) return MSMP_OK;
     const PackedLayout L = packed_layout(tw, nv);
     EdgeArgs a{h, u, pos, vars, tgt, col, nullptr, (long)n_edges, (long)n_nodes, 0, tw, nv, L.nc1,
-               packed + L.w1, packed + L.w2, packed + L.b1, packed + L.b2, nullptr, nullptr, msg_out, nullptr};
+               packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, nullptr, nullptr, msg_out, nullptr};
     constexpr int NB = 2;
     const unsigned grid = (unsigned)((n_edges + 128 * NB - 1) / (128 * NB));
     timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
@@ -470,10 +511,12 @@ extern "C" int msmp_node_project_f32(const float* h, const float* u, const float
     return check_launch("node_proj_kernel");
 }
 
+static int g_split = 0;      // msmp_tune("split", 1): fp16-split matrix path where built
 static int g_edge_nb = 0;    // tuning override (msmp_tune): 0 = automatic, 1 / 2 = force the tile size of the factorised kernel
 
 extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
+    if (key && !strcmp(key, "split")) { g_split = value; return MSMP_OK; }
     msmp::set_error("msmp_tune: unknown key");
     return MSMP_ERR_ARG;
 }
@@ -500,10 +543,11 @@ static int edge_aggregate(const float* h, const float* u, const float* pos, cons
     int tile_nodes = max_in_degree > 0 ? edges_per_tile / max_in_degree : edges_per_tile;
     if (tile_nodes > 256) tile_nodes = 256;      // keeps the per-tile node loop short when degrees are tiny
     EdgeArgs a{h, u, pos, vars, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, tw, nv, L.nc1,
-               packed + L.w1, packed + L.w2, packed + L.b1, packed + L.b2, P, Q, nullptr, agg_out};
+               packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, P, Q, nullptr, agg_out};
     const unsigned grid = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
     timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
-    if (P && edges_per_tile == 128) hipLaunchKernelGGL((edge_mlp_kernel<1, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (P && edges_per_tile == 128 && g_split) hipLaunchKernelGGL((edge_mlp_kernel_occ2<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else if (P && edges_per_tile == 128) hipLaunchKernelGGL((edge_mlp_kernel<1, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (P) hipLaunchKernelGGL((edge_mlp_kernel<2, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((edge_mlp_kernel<2, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     timing_end(MSMP_K_EDGE_MLP, (hipStream_t)stream);

@@ -90,7 +90,12 @@ def test_pack_layer_layout(mp):
         w3v = blob[o:o + H * 8].reshape(H, 8); o += H * 8
         w1 = blob[o:o + nc1 * 4096].reshape(nc1, H, 32); o += nc1 * 4096
         w2 = blob[o:o + 4 * 4096].reshape(4, H, 32); o += 4 * 4096
+        split = blob[o:o + (16 + nc1) * 4096].view(np.float16).reshape(-1, 2, 4, 2, 64, 8)   # [chunk][s][T][plane][lane][j]
+        o += (16 + nc1) * 4096
+        scales = blob[o:o + 8]; o += 8
         assert o == blob.size
+        for i, k in enumerate(('message_net_1.0.weight', 'message_net_2.0.weight', 'update_net_1.0.weight', 'update_net_2.0.weight')):
+            assert 16 <= np.abs(sd[k]).max() * scales[i] < 32 and scales[i] * scales[4 + i] == 1.0    # exact powers of two
         un = lambda c: np.transpose(c, (1, 0, 2)).reshape(H, -1)
         k1 = 2 * H + tw + 1 + nv
         assert np.array_equal(un(w1)[:, :k1], sd['message_net_1.0.weight']) and not un(w1)[:, k1:].any()
@@ -100,6 +105,26 @@ def test_pack_layer_layout(mp):
         assert np.array_equal(un(w4), sd['update_net_2.0.weight'])
         for i, k in enumerate(('message_net_1.0.bias', 'message_net_2.0.bias', 'update_net_1.0.bias', 'update_net_2.0.bias')):
             assert np.array_equal(b[i], sd[k])
+        # fp16-split copies: hi + lo * 2^-11 reproduces every weight to 2^-22 relative, in the documented k orders
+        def unsplit(chunks, acc_order):
+            hi, lo = chunks[:, :, :, 0].astype(np.float64), chunks[:, :, :, 1].astype(np.float64)
+            val = hi + lo                                            # [chunk][s][T][lane][j]
+            out = np.zeros((H, 32 * chunks.shape[0]))
+            for c_ in range(chunks.shape[0]):
+                for s_ in range(2):
+                    for T_ in range(4):
+                        for ln in range(64):
+                            r_, h_ = 32 * T_ + (ln & 31), ln >> 5
+                            for j_ in range(8):
+                                k_ = 16 * s_ + (8 * (j_ >> 2) + 4 * h_ + (j_ & 3) if acc_order else 8 * h_ + j_)
+                                out[r_, 32 * c_ + k_] = val[c_, s_, T_, ln, j_]
+            return out
+        tol = lambda ref: 2.0 ** -22 * np.abs(ref).max() + 1e-9
+        w3s, w4s, w1s, w2s = split[:8], split[8:12], split[12:12 + nc1], split[12 + nc1:]
+        assert np.abs(unsplit(w3s, False) * scales[6] - sd['update_net_1.0.weight'][:, :2 * H]).max() < tol(sd['update_net_1.0.weight'])
+        assert np.abs(unsplit(w4s, True) * scales[7] - sd['update_net_2.0.weight']).max() < tol(sd['update_net_2.0.weight'])
+        assert np.abs(unsplit(w1s, False)[:, :k1] * scales[4] - sd['message_net_1.0.weight']).max() < tol(sd['message_net_1.0.weight'])
+        assert np.abs(unsplit(w2s, True) * scales[5] - sd['message_net_2.0.weight']).max() < tol(sd['message_net_2.0.weight'])
 
 
 @pytest.mark.parametrize('tw,nv,sizes,shuffle', [(25, 2, [100, 100], False), (50, 3, [100, 37, 1, 64], True),
@@ -167,8 +192,17 @@ def test_layer_pieces_vs_oracle(mp, tw, nv, sizes, shuffle):
     ref_agg64 = O.scatter_mean(ref_msg, ei_csr[1], n)
     e_fact = np.abs(agg_p.double().cpu().numpy() - ref_agg64).max() / max(1.0, np.abs(ref_agg64).max())
     e_dense = np.abs(agg.double().cpu().numpy() - ref_agg64).max() / max(1.0, np.abs(ref_agg64).max())
-    print(f'agg error vs float64: factorised {e_fact:.2e}, dense {e_dense:.2e}')
-    assert e_fact < 1e-6
+    # the same on the fp16 matrix pipe (2-way fp16 split of both operands): fp32-class accuracy is the requirement
+    agg_s = torch.full((n, H), float('nan'), device='cuda')
+    L.msmp_tune(b'split', 1)
+    try:
+        check(L.msmp_edge_aggregate_projected_f32(ptr(P), ptr(Q), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt), n, e,
+                                                  gs.max_in_degree, tw, nv, ptr(blob), ptr(agg_s), st), 'edge_aggregate_projected split')
+    finally:
+        L.msmp_tune(b'split', 0)
+    e_split = np.abs(agg_s.double().cpu().numpy() - ref_agg64).max() / max(1.0, np.abs(ref_agg64).max())
+    print(f'agg error vs float64: factorised {e_fact:.2e}, dense {e_dense:.2e}, fp16-split {e_split:.2e}')
+    assert e_fact < 1e-6 and e_split < 1e-6
 
     for mode, lin in ((1, True), (0, False)):
         out = torch.empty(n, H, device='cuda')
