@@ -64,7 +64,8 @@ __global__ void pack_layer_kernel(PackArgs a) {
     const PackedLayout L = packed_layout(a.tw, a.nv);
     const int k1 = 2 * H + a.tw + 1 + a.nv;   // in-features of message_net_1
     const int k3 = 2 * H + a.nv;              // in-features of update_net_1
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < L.w3s; p += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < L.w1s; p += (int64_t)gridDim.x * blockDim.x) {
+        if (p >= L.w3s && p < L.w1) continue;  // split copies and scales: written by the two kernels below
         float v = 0.f;
         if (p < L.w4) {                       // w3 chunks
             const int64_t o = p - L.w3;
@@ -78,7 +79,7 @@ __global__ void pack_layer_kernel(PackArgs a) {
         else if (p < L.b3) v = a.b2[p - L.b2];
         else if (p < L.b4) v = a.b3[p - L.b3];
         else if (p < L.w3v) v = a.b4[p - L.b4];
-        else if (p < L.w1) {                  // variables columns of update_net_1
+        else if (p < L.w3s) {                 // variables columns of update_net_1
             const int64_t o = p - L.w3v;
             const int row = (int)(o / MSMP_MAX_VARS), vv = (int)(o % MSMP_MAX_VARS);
             v = vv < a.nv ? a.w3[(size_t)row * k3 + 2 * H + vv] : 0.f;
@@ -127,9 +128,10 @@ __global__ __launch_bounds__(256) void pack_layer_scale_kernel(PackArgs a) {
 __global__ void pack_layer_split_kernel(PackArgs a) {
     const PackedLayout L = packed_layout(a.tw, a.nv);
     const int k1 = 2 * H + a.tw + 1 + a.nv, k3 = 2 * H + a.nv;
-    _Float16* out = reinterpret_cast<_Float16*>(a.out + L.w3s);
+    _Float16* out_a = reinterpret_cast<_Float16*>(a.out + L.w3s);     // w3s, w4s
+    _Float16* out_b = reinterpret_cast<_Float16*>(a.out + L.w1s);     // w1s, w2s
     const float* sc = a.out + L.scales;
-    const int64_t n_half = (L.scales - L.w3s) * 2;
+    const int64_t n_half = (int64_t)(12 + L.nc1 + 4) * 8192;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_half; p += (int64_t)gridDim.x * blockDim.x) {
         int ch = (int)(p >> 13);
         const int idx = (int)(p & 8191);
@@ -147,7 +149,9 @@ __global__ void pack_layer_split_kernel(PackArgs a) {
             w = a.w2[(size_t)row * H + 32 * (ch - 12 - L.nc1) + split_k_acc(s, h, j)] * sc[1];
         }
         const _Float16 hi = (_Float16)w;
-        out[p] = plane == 0 ? hi : (_Float16)(w - (float)hi);
+        const _Float16 val = plane == 0 ? hi : (_Float16)(w - (float)hi);
+        if (ch < 12) out_a[p] = val;
+        else out_b[p - 12 * 8192] = val;
     }
 }
 

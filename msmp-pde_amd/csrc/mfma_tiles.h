@@ -163,6 +163,16 @@ __device__ __forceinline__ void acc_init_bias_scaled(const float* __restrict__ b
         }
 }
 
+template <int NB>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[4][NB]) {
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[T][nb][r] = 0.f;
+}
+
 // Host/device: value of element (s, T, plane, lane, j) of a split chunk built from W[row][k0 + k] (row stride ld).
 __host__ __device__ inline int split_k_natural(int s, int h, int j) { return 16 * s + 8 * h + j; }
 __host__ __device__ inline int split_k_acc(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }

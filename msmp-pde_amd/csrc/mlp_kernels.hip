@@ -474,9 +474,182 @@ __global__ __launch_bounds__(256) void node_update_kernel(NodeArgs a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// fp16-split editions of the two node kernels (mfma_tiles.h).  B fragments in natural k order: lane (n, h)
+// takes the 8 consecutive features 16s + 8h .. +7 of each K = 16 step (two 16-B loads of the node row).
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gather_split_row(const float* __restrict__ row32, int hh, half8 (&bhi)[1][2], half8 (&blo)[1][2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(row32 + 16 * s + 8 * hh);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(row32 + 16 * s + 8 * hh + 4);
+        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        split8(v, bhi[0][s], blo[0][s]);
+    }
+}
+
+struct ProjSplitArgs {
+    ProjArgs b;
+    const float* w1s;     // nc1 split chunks (natural order)
+    const float* scales;  // [8]
+};
+
+__global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs sa) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS];
+    const ProjArgs& a = sa.b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const long n = (long)blockIdx.x * 128 + wave * 32 + c;
+    const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
+    const float sc = sa.scales[0], inv = sa.scales[4];
+
+    f32x16 p[4][1], qa[4][1];
+    acc_init_bias_scaled<1>(a.b1, sc, hh, p);
+    acc_zero<1>(qa);
+    WStage ws;
+    wstage_load(ws, sa.w1s, tid);
+    wstage_store_linear(ws, lds, tid);
+    __syncthreads();
+    const float* hp = a.h + (size_t)nc * H;
+    for (int ch = 0; ch < 8; ++ch) {
+        wstage_load(ws, sa.w1s + (size_t)(ch + 1) * SPLIT_CHUNK_FLOATS, tid);
+        half8 bhi[1][2], blo[1][2];
+        gather_split_row(hp + 32 * (ch & 3), hh, bhi, blo);
+        if (ch < 4) mma_chunk_split<1>(lds + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, p);
+        else mma_chunk_split<1>(lds + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, qa);
+        wstage_store_linear(ws, lds + ((ch + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+        __syncthreads();
+    }
+    const float* un = a.u + (size_t)nc * a.tw;
+    for (int ch = 8; ch < a.nc1; ++ch) {
+        if (ch + 1 < a.nc1) wstage_load(ws, sa.w1s + (size_t)(ch + 1) * SPLIT_CHUNK_FLOATS, tid);
+        half8 phi[1][2], plo[1][2], qhi[1][2], qlo[1][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float vp[8], vq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 32 * (ch - 8) + 16 * s + 8 * hh + j;
+                float x = 0.f, y = 0.f;
+                if (k < a.tw) { x = un[k]; y = -x; }
+                else if (k == a.tw) { x = a.pos[nc]; y = -x; }
+                else if (k <= a.tw + a.nv) x = a.vars[(size_t)nc * a.nv + (k - a.tw - 1)];
+                vp[j] = x;
+                vq[j] = y;
+            }
+            split8(vp, phi[0][s], plo[0][s]);
+            split8(vq, qhi[0][s], qlo[0][s]);
+        }
+        mma_chunk_split<1>(lds + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, phi, plo, p);
+        mma_chunk_split<1>(lds + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, qhi, qlo, qa);
+        if (ch + 1 < a.nc1) wstage_store_linear(ws, lds + ((ch + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+        __syncthreads();
+    }
+    if (n < a.n_nodes) {
+        float* po = a.P + (size_t)n * H + 4 * hh;
+        float* qo = a.Q + (size_t)n * H + 4 * hh;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v, w;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { v[m] = p[T][0][4 * q + m] * inv; w[m] = qa[T][0][4 * q + m] * inv; }
+                *reinterpret_cast<f32x4*>(po + 32 * T + 8 * q) = v;
+                *reinterpret_cast<f32x4*>(qo + 32 * T + 8 * q) = w;
+            }
+    }
+}
+
+struct NodeSplitArgs {
+    NodeArgs b;
+    const float* w3s;     // 8 split chunks (natural), followed by w4s: 4 split chunks (acc order)
+    const float* scales;  // [8]
+};
+
+__global__ __launch_bounds__(256, 2) void node_update_split_kernel(NodeSplitArgs sa) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS];
+    const NodeArgs& a = sa.b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const long n = (long)blockIdx.x * 128 + wave * 32 + c;
+    const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
+    const float sc3 = sa.scales[2], inv3 = sa.scales[6], sc4 = sa.scales[3], inv4 = sa.scales[7];
+
+    // acc init = (b3 + W3[:, 256:256+nv] vars_n) * 2^s3
+    f32x16 z[4][1];
+    acc_init_bias<1>(a.b3, hh, z);
+    for (int v = 0; v < a.nv; ++v) {
+        const float xv = a.vars[(size_t)nc * a.nv + v];
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                z[T][0][r] = fmaf(a.w3v[(32 * T + acc_row(r, hh)) * MSMP_MAX_VARS + v], xv, z[T][0][r]);
+    }
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[T][0][r] *= sc3;
+
+    WStage ws;
+    wstage_load(ws, sa.w3s, tid);
+    wstage_store_linear(ws, lds, tid);
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < 8; ++ch) {
+        wstage_load(ws, sa.w3s + (size_t)(ch + 1) * SPLIT_CHUNK_FLOATS, tid);      // chunk 8 = w4s chunk 0
+        half8 bhi[1][2], blo[1][2];
+        gather_split_row((ch < 4 ? a.h : a.agg) + (size_t)nc * H + 32 * (ch & 3), hh, bhi, blo);
+        mma_chunk_split<1>(lds + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, z);
+        wstage_store_linear(ws, lds + ((ch + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[T][0][r] = swishf(z[T][0][r] * inv3);
+
+    f32x16 y[4][1];
+    acc_init_bias_scaled<1>(a.b4, sc4, hh, y);
+    const float* w4s = sa.w3s + 8 * SPLIT_CHUNK_FLOATS;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t < 3) wstage_load(ws, w4s + (size_t)(t + 1) * SPLIT_CHUNK_FLOATS, tid);
+        half8 bhi[1][2], blo[1][2];
+        split_acc_tile<1>(z[t], bhi, blo);
+        mma_chunk_split<1>(lds + (t & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, y);
+        if (t < 3) {
+            wstage_store_linear(ws, lds + ((t + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+            __syncthreads();
+        }
+    }
+    if (n < a.n_nodes) {
+        float* o = a.out + (size_t)n * H + 4 * hh;
+        const float* hx = a.h + (size_t)n * H + 4 * hh;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+                if (a.mode == MSMP_LAYER_LIN) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) v[m] = y[T][0][4 * q + m] * inv4;
+                } else {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(hx + 32 * T + 8 * q);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) v[m] = x[m] + swishf(y[T][0][4 * q + m] * inv4);
+                }
+                *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = v;
+            }
+    }
+}
+
 }  // namespace msmp
 
 using namespace msmp;
+
+static int g_split = 0;      // msmp_tune("split", 1): fp16-split matrix path where built
 
 extern "C" int msmp_edge_mlp_f32(const float* h, const float* u, const float* pos, const float* vars,
                                  const int32_t* tgt, const int32_t* col, int64_t n_nodes, int64_t n_edges,
@@ -506,12 +679,15 @@ extern "C" int msmp_node_project_f32(const float* h, const float* u, const float
     ProjArgs a{h, u, pos, vars, (long)n_nodes, tw, nv, L.nc1, packed + L.w1, packed + L.b1, p_out, q_out};
     const unsigned grid = (unsigned)((n_nodes + 127) / 128);
     timing_begin(MSMP_K_NODE_PROJ, (hipStream_t)stream);
-    hipLaunchKernelGGL(node_proj_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (g_split) {
+        ProjSplitArgs sa{a, packed + L.w1s, packed + L.scales};
+        hipLaunchKernelGGL(node_proj_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, sa);
+    } else
+        hipLaunchKernelGGL(node_proj_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     timing_end(MSMP_K_NODE_PROJ, (hipStream_t)stream);
     return check_launch("node_proj_kernel");
 }
 
-static int g_split = 0;      // msmp_tune("split", 1): fp16-split matrix path where built
 static int g_edge_nb = 0;    // tuning override (msmp_tune): 0 = automatic, 1 / 2 = force the tile size of the factorised kernel
 
 extern "C" int msmp_tune(const char* key, int value) {
@@ -583,7 +759,11 @@ extern "C" int msmp_node_update_f32(const float* h, const float* agg, const floa
     constexpr int NB = 1;
     const unsigned grid = (unsigned)((n_nodes + 128 * NB - 1) / (128 * NB));
     timing_begin(MSMP_K_NODE_UPDATE, (hipStream_t)stream);
-    hipLaunchKernelGGL(node_update_kernel<NB>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (g_split) {
+        NodeSplitArgs sa{a, packed + L.w3s, packed + L.scales};
+        hipLaunchKernelGGL(node_update_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, sa);
+    } else
+        hipLaunchKernelGGL(node_update_kernel<NB>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     timing_end(MSMP_K_NODE_UPDATE, (hipStream_t)stream);
     return check_launch("node_update_kernel");
 }

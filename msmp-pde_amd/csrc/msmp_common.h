@@ -16,18 +16,19 @@ constexpr int CHUNK_FLOATS = H * KC;    // one packed chunk: [128 out][32 k]
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-// Packed layer blob (floats).  Chunks are [128 out][32 k] row-major, k ascending, zero padded.
-// Sections whose size does not depend on tw come first, so the node kernels need no tw:
+// Packed layer blob (floats).  Chunks are [128 out][32 k] row-major, k ascending, zero padded; "split chunks"
+// are the fp16-split copies of mfma_tiles.h (16 KB each, same footprint).  Sections whose size does not
+// depend on tw come first, so the node kernels need no tw:
 //   w3 (8 chunks: h | agg columns of update_net_1) | w4 (4 chunks) | b1 b2 b3 b4 ([128] each) |
 //   w3v [128][MSMP_MAX_VARS] (variables columns of update_net_1) |
+//   w3s (8 split chunks, natural k order) | w4s (4, acc order) | scales [8]: 2^s of w1..w4, then 2^-s of w1..w4 |
 //   w1 (nc1 chunks: h_i | h_j | u_i-u_j, p_i-p_j, vars_i, 0-pad) | w2 (4 chunks) |
-//   fp16-split copies (mfma_tiles.h, 16 KB "split chunks"): w3s (8, natural k order) | w4s (4, acc order) |
-//   w1s (nc1, natural) | w2s (4, acc order) | scales [8]: 2^s of w1..w4 then 2^-s of w1..w4 (split copies only)
+//   w1s (nc1 split chunks, natural) | w2s (4, acc order)
 // w4 directly follows w3 and w2 directly follows w1 (also in the split copies): the staging pipeline
 // prefetches across the seam.
 struct PackedLayout {
     int nc1;        // chunks of W1 (4 h_i + 4 h_j + tail chunks)
-    int64_t w3, w4, b1, b2, b3, b4, w3v, w1, w2, w3s, w4s, w1s, w2s, scales, total;
+    int64_t w3, w4, b1, b2, b3, b4, w3v, w3s, w4s, scales, w1, w2, w1s, w2s, total;
 };
 
 __host__ __device__ inline int tail_chunks(int tw, int nv) { return (tw + 1 + nv + KC - 1) / KC; }
@@ -43,13 +44,13 @@ __host__ __device__ inline PackedLayout packed_layout(int tw, int nv) {
     L.b3 = o; o += H;
     L.b4 = o; o += H;
     L.w3v = o; o += H * MSMP_MAX_VARS;
-    L.w1 = o; o += (int64_t)L.nc1 * CHUNK_FLOATS;
-    L.w2 = o; o += 4 * CHUNK_FLOATS;
     L.w3s = o; o += 8 * CHUNK_FLOATS;
     L.w4s = o; o += 4 * CHUNK_FLOATS;
+    L.scales = o; o += 8;
+    L.w1 = o; o += (int64_t)L.nc1 * CHUNK_FLOATS;
+    L.w2 = o; o += 4 * CHUNK_FLOATS;
     L.w1s = o; o += (int64_t)L.nc1 * CHUNK_FLOATS;
     L.w2s = o; o += 4 * CHUNK_FLOATS;
-    L.scales = o; o += 8;
     L.total = o;
     return L;
 }

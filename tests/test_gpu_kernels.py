@@ -88,11 +88,14 @@ def test_pack_layer_layout(mp):
         w4 = blob[o:o + 4 * 4096].reshape(4, H, 32); o += 4 * 4096
         b = blob[o:o + 4 * H].reshape(4, H); o += 4 * H
         w3v = blob[o:o + H * 8].reshape(H, 8); o += H * 8
+        sh = lambda a: a.view(np.float16).reshape(-1, 2, 4, 2, 64, 8)           # [chunk][s][T][plane][lane][j]
+        w3s = sh(blob[o:o + 8 * 4096]); o += 8 * 4096
+        w4s = sh(blob[o:o + 4 * 4096]); o += 4 * 4096
+        scales = blob[o:o + 8]; o += 8
         w1 = blob[o:o + nc1 * 4096].reshape(nc1, H, 32); o += nc1 * 4096
         w2 = blob[o:o + 4 * 4096].reshape(4, H, 32); o += 4 * 4096
-        split = blob[o:o + (16 + nc1) * 4096].view(np.float16).reshape(-1, 2, 4, 2, 64, 8)   # [chunk][s][T][plane][lane][j]
-        o += (16 + nc1) * 4096
-        scales = blob[o:o + 8]; o += 8
+        w1s = sh(blob[o:o + nc1 * 4096]); o += nc1 * 4096
+        w2s = sh(blob[o:o + 4 * 4096]); o += 4 * 4096
         assert o == blob.size
         for i, k in enumerate(('message_net_1.0.weight', 'message_net_2.0.weight', 'update_net_1.0.weight', 'update_net_2.0.weight')):
             assert 16 <= np.abs(sd[k]).max() * scales[i] < 32 and scales[i] * scales[4 + i] == 1.0    # exact powers of two
@@ -120,7 +123,6 @@ def test_pack_layer_layout(mp):
                                 out[r_, 32 * c_ + k_] = val[c_, s_, T_, ln, j_]
             return out
         tol = lambda ref: 2.0 ** -22 * np.abs(ref).max() + 1e-9
-        w3s, w4s, w1s, w2s = split[:8], split[8:12], split[12:12 + nc1], split[12 + nc1:]
         assert np.abs(unsplit(w3s, False) * scales[6] - sd['update_net_1.0.weight'][:, :2 * H]).max() < tol(sd['update_net_1.0.weight'])
         assert np.abs(unsplit(w4s, True) * scales[7] - sd['update_net_2.0.weight']).max() < tol(sd['update_net_2.0.weight'])
         assert np.abs(unsplit(w1s, False)[:, :k1] * scales[4] - sd['message_net_1.0.weight']).max() < tol(sd['message_net_1.0.weight'])
@@ -194,15 +196,27 @@ def test_layer_pieces_vs_oracle(mp, tw, nv, sizes, shuffle):
     e_dense = np.abs(agg.double().cpu().numpy() - ref_agg64).max() / max(1.0, np.abs(ref_agg64).max())
     # the same on the fp16 matrix pipe (2-way fp16 split of both operands): fp32-class accuracy is the requirement
     agg_s = torch.full((n, H), float('nan'), device='cuda')
+    Ps, Qs = torch.empty(n, H, device='cuda'), torch.empty(n, H, device='cuda')
     L.msmp_tune(b'split', 1)
     try:
-        check(L.msmp_edge_aggregate_projected_f32(ptr(P), ptr(Q), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt), n, e,
+        check(L.msmp_node_project_f32(ptr(dh), ptr(du), ptr(dpos), ptr(dvar), n, tw, nv, ptr(blob), ptr(Ps), ptr(Qs), st), 'node_project split')
+        check(L.msmp_edge_aggregate_projected_f32(ptr(Ps), ptr(Qs), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt), n, e,
                                                   gs.max_in_degree, tw, nv, ptr(blob), ptr(agg_s), st), 'edge_aggregate_projected split')
+        outs_split = []
+        for mode in (1, 0):
+            o_ = torch.empty(n, H, device='cuda')
+            check(L.msmp_node_update_f32(ptr(dh), ptr(agg), ptr(dvar), n, nv, ptr(blob), mode, ptr(o_), st), 'node split')
+            outs_split.append(o_)
     finally:
         L.msmp_tune(b'split', 0)
-    e_split = np.abs(agg_s.double().cpu().numpy() - ref_agg64).max() / max(1.0, np.abs(ref_agg64).max())
-    print(f'agg error vs float64: factorised {e_fact:.2e}, dense {e_dense:.2e}, fp16-split {e_split:.2e}')
-    assert e_fact < 1e-6 and e_split < 1e-6
+    relerr = lambda t, ref: np.abs(t.double().cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+    e_split = relerr(agg_s, ref_agg64)
+    print(f'agg error vs float64: factorised {e_fact:.2e}, dense {e_dense:.2e}, fp16-split {e_split:.2e};  '
+          f'P/Q error: fp32 {relerr(P, ref_P):.2e}/{relerr(Q, ref_Q):.2e}, fp16-split {relerr(Ps, ref_P):.2e}/{relerr(Qs, ref_Q):.2e}')
+    assert e_fact < 1e-6 and e_split < 1e-6 and relerr(Ps, ref_P) < 1e-6 and relerr(Qs, ref_Q) < 1e-6
+    for o_, lin_ in zip(outs_split, (True, False)):
+        ref_ = O.node_update(p, h64, agg.double().cpu().numpy(), var64, lin_)
+        assert relerr(o_, ref_) < 1e-6, ('node_update split', lin_, relerr(o_, ref_))
 
     for mode, lin in ((1, True), (0, False)):
         out = torch.empty(n, H, device='cuda')
