@@ -47,8 +47,10 @@ typedef void* msmp_stream_t;
 
 int msmp_version(void);
 const char* msmp_last_error(void);
-/* Tuning knobs for A/B measurements (not part of the data contract). key "edge_nb": 0 auto, 1 / 2 force the
- * 128- / 256-edge tile of the factorised message kernel. */
+/* Knobs for A/B measurements and validation (not part of the data contract):
+ *   "split"   1 (default): the GEMMs of the node / edge / LEM kernels run on the fp16 matrix pipe with a 2-way
+ *             fp16 split of both operands (fp32-class accuracy); 0: the fp32-MFMA kernels.
+ *   "edge_nb" 0 auto, 1 / 2 force the 128- / 256-edge tile of the factorised message kernel. */
 int msmp_tune(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------

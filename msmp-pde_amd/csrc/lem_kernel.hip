@@ -27,8 +27,11 @@ constexpr int LEM_MAX_INP = 8;
 //   wxf [4 groups: g1,g2,g3,lin][4 T][4 s][64 lanes]: the input columns as MFMA A fragments, value
 //        = W[128*group + 32T + (lane & 31)][H + 2s + (lane >> 5)] (0 past ninp) |
 //   mlp bias [256] (ba, bb)
+//   fp16-split copies for the split kernel (mfma_tiles.h): scales [8] (2^s of W, Wz, Wa, Wb, then 2^-s) |
+//   rec_s (16 split chunks, acc order, same consumption order) | mlp_s (8 split chunks) |
+//   bias_s [512], wxf_s [4096], mlpb_s [256]: the fp32 bias / input-column fragments pre-multiplied by 2^s of their matrix
 struct LemLayout {
-    int64_t rec, mlp, bias, wx, mlpb, total;
+    int64_t rec, mlp, bias, wx, mlpb, scales, rec_s, mlp_s, bias_s, wx_s, mlpb_s, total;
 };
 
 __host__ __device__ inline LemLayout lem_layout() {
@@ -39,6 +42,12 @@ __host__ __device__ inline LemLayout lem_layout() {
     L.bias = o; o += 4 * H;
     L.wx = o; o += 4 * H * LEM_MAX_INP;
     L.mlpb = o; o += 2 * H;
+    L.scales = o; o += 8;
+    L.rec_s = o; o += 16 * CHUNK_FLOATS;
+    L.mlp_s = o; o += 8 * CHUNK_FLOATS;
+    L.bias_s = o; o += 4 * H;
+    L.wx_s = o; o += 4 * H * LEM_MAX_INP;
+    L.mlpb_s = o; o += 2 * H;
     L.total = o;
     return L;
 }
@@ -52,7 +61,7 @@ struct LemPackArgs {
 __global__ void pack_lem_kernel(LemPackArgs a) {
     const LemLayout L = lem_layout();
     const int kin = H + a.ninp;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < L.total; p += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < L.scales; p += (int64_t)gridDim.x * blockDim.x) {
         float v = 0.f;
         if (p < L.mlp) {
             const int ch = (int)(p / CHUNK_FLOATS), row = (int)(p % CHUNK_FLOATS) / KC, kk = (int)(p % KC);
@@ -81,6 +90,58 @@ __global__ void pack_lem_kernel(LemPackArgs a) {
         }
         a.out[p] = v;
     }
+}
+
+// scales[i] = 2^s with max|M_i| 2^s in [16, 32) for M = (W, Wz, Wa, Wb); scales[4+i] = 2^-s.  grid = 4.
+__global__ __launch_bounds__(256) void pack_lem_scale_kernel(LemPackArgs a) {
+    __shared__ float red[256];
+    const LemLayout L = lem_layout();
+    const int kin = H + a.ninp;
+    const float* w = blockIdx.x == 0 ? a.w : blockIdx.x == 1 ? a.wz : blockIdx.x == 2 ? a.wa : a.wb;
+    const int n = blockIdx.x == 0 ? 3 * H * kin : blockIdx.x == 1 ? H * kin : H * H;
+    float m = 0.f;
+    if (w) for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mx = red[0];
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);
+        const int sft = mx > 0.f ? 5 - e : 0;
+        a.out[L.scales + blockIdx.x] = ldexpf(1.0f, sft);
+        a.out[L.scales + 4 + blockIdx.x] = ldexpf(1.0f, -sft);
+    }
+}
+
+// split copies: rec_s / mlp_s from the fp32 chunks already in the blob (value at [row][k] of chunk ch -> acc order),
+// and the scaled bias / input fragments.
+__global__ void pack_lem_split_kernel(LemPackArgs a) {
+    const LemLayout L = lem_layout();
+    const float* sc = a.out + L.scales;
+    _Float16* out = reinterpret_cast<_Float16*>(a.out + L.rec_s);
+    const int64_t n_half = (int64_t)24 * 8192;
+    const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = tid0; p < n_half; p += stride) {
+        const int ch = (int)(p >> 13), idx = (int)(p & 8191);
+        const int j = idx & 7, lane = (idx >> 3) & 63, plane = (idx >> 9) & 1, T = (idx >> 10) & 3, s = (idx >> 12) & 1;
+        const int row = 32 * T + (lane & 31), h = lane >> 5;
+        const float* src = ch < 16 ? a.out + L.rec + (size_t)ch * CHUNK_FLOATS : a.out + L.mlp + (size_t)(ch - 16) * CHUNK_FLOATS;
+        // matrix of the chunk: rec groups g2, g3, g1 -> W (scale 0), lin -> Wz (1); mlp Wa (2), Wb (3)
+        const int mi = ch < 12 ? 0 : ch < 16 ? 1 : ch < 20 ? 2 : 3;
+        const float w = src[row * KC + split_k_acc(s, h, j)] * sc[mi];
+        const _Float16 hi = (_Float16)w;
+        out[p] = plane == 0 ? hi : (_Float16)(w - (float)hi);
+    }
+    for (int64_t p = tid0; p < 4 * H; p += stride)           // bias rows: g1, g2, g3 (W), bz (Wz)
+        a.out[L.bias_s + p] = a.out[L.bias + p] * sc[p < 3 * H ? 0 : 1];
+    for (int64_t p = tid0; p < 4 * H * LEM_MAX_INP; p += stride)   // wxf groups g1, g2, g3 (W), lin (Wz)
+        a.out[L.wx_s + p] = a.out[L.wx + p] * sc[(p >> 10) < 3 ? 0 : 1];
+    for (int64_t p = tid0; p < 2 * H; p += stride)
+        a.out[L.mlpb_s + p] = a.out[L.mlpb + p] * sc[p < H ? 2 : 3];
 }
 
 __device__ __forceinline__ float tanhf_(float x) {
@@ -233,10 +294,154 @@ __global__ __launch_bounds__(256) void lem_encoder_kernel(LemArgs a) {
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// fp16-split edition (mfma_tiles.h): same recurrence, the four K = 128 GEMMs per step on the fp16 matrix pipe.
+// The states stay fp32 in accumulator layout; y is split into hi/lo fragments once per step (shared by the three
+// gate GEMMs), z once (for the lin GEMM, in the same registers).  Input columns remain NS fp32 MFMA k-steps, with
+// bias and fragments pre-multiplied by the matrix's 2^s so that they accumulate into the same scaled accumulator.
+// ----------------------------------------------------------------------------------------------
+struct LemSplitArgs {
+    LemArgs b;            // rec / mlp point at the SPLIT chunks, bias / wx / mlpb at the pre-scaled copies
+    const float* scales;  // [8]
+};
+
+template <int NS>
+__device__ __forceinline__ void lem_acc_init_s(const LemArgs& a, int grp, int lane, int hh, const float (&x)[2 * NS],
+                                               f32x16 (&acc)[4][1]) {
+    acc_init_bias<1>(a.bias + H * grp, hh, acc);
+    const float* wf = a.wx + (size_t)grp * 1024 + lane;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float b = hh ? x[2 * s + 1] : x[2 * s];
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+            acc[T][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[(T * 4 + s) * 64], b, acc[T][0], 0, 0, 0);
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void lem_encoder_split_kernel(LemSplitArgs sa) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS];
+    const LemArgs& a = sa.b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const long n = (long)blockIdx.x * 128 + wave * 32 + c;
+    const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
+    const float* xrow = a.xin + (size_t)nc * a.t_len * (2 * NS);
+    const float invW = sa.scales[4], invZ = sa.scales[5];
+
+    f32x16 y[4][1], z[4][1], g[4][1], acc[4][1];
+    half8 sh[4][1][2], sl[4][1][2];            // hi / lo fragments of the state currently used as B operand
+    acc_zero<1>(y);
+    acc_zero<1>(z);
+#pragma unroll
+    for (int T = 0; T < 4; ++T) split_acc_tile<1>(y[T], sh[T], sl[T]);
+
+    WStage ws;
+    wstage_load(ws, a.rec, tid);
+    wstage_store_linear(ws, lds, tid);
+    __syncthreads();
+
+#define LEM_GROUP_S(ACC, BASE, NEXT_AFTER_LAST)                                                        \
+    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                 \
+        const float* nxt = kc < 3 ? a.rec + (size_t)((BASE) + kc + 1) * SPLIT_CHUNK_FLOATS : (NEXT_AFTER_LAST); \
+        wstage_load(ws, nxt, tid);                                                                     \
+        mma_chunk_split<1>(lds + (((BASE) + kc) & 1) * SPLIT_CHUNK_FLOATS, lane, sh[kc], sl[kc], ACC);  \
+        wstage_store_linear(ws, lds + (((BASE) + kc + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);              \
+        __syncthreads();                                                                               \
+    }
+
+    for (int t = 0; t < a.t_len; ++t) {
+        float x[2 * NS];
+#pragma unroll
+        for (int f = 0; f < 2 * NS; ++f) x[f] = xrow[t * (2 * NS) + f];
+        const float* after = t + 1 == a.t_len ? a.mlp : a.rec;
+
+        lem_acc_init_s<NS>(a, 1, lane, hh, x, g);                    // g2 -> dt_
+        LEM_GROUP_S(g, 0, a.rec + 4 * SPLIT_CHUNK_FLOATS)
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[T][0][r] = a.dt * sigmoidf_(g[T][0][r] * invW);
+        lem_acc_init_s<NS>(a, 2, lane, hh, x, acc);                  // g3 -> z update
+        LEM_GROUP_S(acc, 4, a.rec + 8 * SPLIT_CHUNK_FLOATS)
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                z[T][0][r] = (1.0f - g[T][0][r]) * z[T][0][r] + g[T][0][r] * tanhf_(acc[T][0][r] * invW);
+        lem_acc_init_s<NS>(a, 0, lane, hh, x, g);                    // g1 -> dt_bar (still from the y fragments)
+        LEM_GROUP_S(g, 8, a.rec + 12 * SPLIT_CHUNK_FLOATS)
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[T][0][r] = a.dt * sigmoidf_(g[T][0][r] * invW);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) split_acc_tile<1>(z[T], sh[T], sl[T]);      // fragments now hold the new z
+        lem_acc_init_s<NS>(a, 3, lane, hh, x, acc);                  // lin -> y update
+        LEM_GROUP_S(acc, 12, after)
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                y[T][0][r] = (1.0f - g[T][0][r]) * y[T][0][r] + g[T][0][r] * tanhf_(acc[T][0][r] * invZ);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) split_acc_tile<1>(y[T], sh[T], sl[T]);      // fragments of the new y
+    }
+#undef LEM_GROUP_S
+
+    if (a.with_mlp) {
+        const float invA = sa.scales[6], invB = sa.scales[7];
+        acc_init_bias<1>(a.mlpb, hh, acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wstage_load(ws, a.mlp + (size_t)(j + 1) * SPLIT_CHUNK_FLOATS, tid);
+            mma_chunk_split<1>(lds + (j & 1) * SPLIT_CHUNK_FLOATS, lane, sh[j], sl[j], acc);
+            wstage_store_linear(ws, lds + ((j + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[T][0][r] = swishf(acc[T][0][r] * invA);
+            split_acc_tile<1>(acc[T], sh[T], sl[T]);
+        }
+        acc_init_bias<1>(a.mlpb + H, hh, y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < 3) wstage_load(ws, a.mlp + (size_t)(4 + j + 1) * SPLIT_CHUNK_FLOATS, tid);
+            mma_chunk_split<1>(lds + (j & 1) * SPLIT_CHUNK_FLOATS, lane, sh[j], sl[j], y);
+            if (j < 3) {
+                wstage_store_linear(ws, lds + ((j + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[T][0][r] = swishf(y[T][0][r] * invB);
+    }
+
+    if (n < a.n_nodes) {
+        float* o = a.out + (size_t)n * H + 4 * hh;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v[m] = y[T][0][4 * q + m];
+                *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = v;
+            }
+    }
+}
+
 }  // namespace msmp
 
 using namespace msmp;
 
+int g_lem_split = 1;     // msmp_tune("split", v) sets it too
 extern "C" int64_t msmp_packed_lem_floats(void) { return lem_layout().total; }
 
 extern "C" int msmp_pack_lem_f32(const float* weights, const float* weights_lin_z, const float* bias, const float* bias_lin_z,
@@ -248,6 +453,8 @@ extern "C" int msmp_pack_lem_f32(const float* weights, const float* weights_lin_
     MSMP_REQUIRE(mlp || !(mlp_w0 || mlp_b0 || mlp_w1 || mlp_b1), MSMP_ERR_ARG, "msmp_pack_lem_f32: give all four mlp tensors or none");
     LemPackArgs a{weights, weights_lin_z, bias, bias_lin_z, mlp_w0, mlp_b0, mlp_w1, mlp_b1, ninp, packed_out};
     hipLaunchKernelGGL(pack_lem_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(pack_lem_scale_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(pack_lem_split_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("pack_lem_kernel");
 }
 
@@ -263,6 +470,17 @@ extern "C" int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len
               packed + L.mlpb, h_out};
     const unsigned grid = (unsigned)((n_nodes + 127) / 128);
     timing_begin(MSMP_K_LEM, (hipStream_t)stream);
+    if (g_lem_split) {
+        LemSplitArgs sa{LemArgs{xin, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s, packed + L.mlp_s, packed + L.bias_s,
+                                packed + L.wx_s, packed + L.mlpb_s, h_out},
+                        packed + L.scales};
+        switch ((ninp + 1) / 2) {
+            case 1: hipLaunchKernelGGL(lem_encoder_split_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sa); break;
+            case 2: hipLaunchKernelGGL(lem_encoder_split_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sa); break;
+            case 3: hipLaunchKernelGGL(lem_encoder_split_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sa); break;
+            default: hipLaunchKernelGGL(lem_encoder_split_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sa); break;
+        }
+    } else
     switch ((ninp + 1) / 2) {
         case 1: hipLaunchKernelGGL(lem_encoder_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;
         case 2: hipLaunchKernelGGL(lem_encoder_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;

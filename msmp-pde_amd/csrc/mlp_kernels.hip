@@ -649,7 +649,8 @@ __global__ __launch_bounds__(256, 2) void node_update_split_kernel(NodeSplitArgs
 
 using namespace msmp;
 
-static int g_split = 0;      // msmp_tune("split", 1): fp16-split matrix path where built
+extern int g_lem_split;
+static int g_split = 1;      // fp16-split matrix path (default); msmp_tune("split", 0) selects the fp32-MFMA kernels
 
 extern "C" int msmp_edge_mlp_f32(const float* h, const float* u, const float* pos, const float* vars,
                                  const int32_t* tgt, const int32_t* col, int64_t n_nodes, int64_t n_edges,
@@ -692,7 +693,7 @@ static int g_edge_nb = 0;    // tuning override (msmp_tune): 0 = automatic, 1 / 
 
 extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
-    if (key && !strcmp(key, "split")) { g_split = value; return MSMP_OK; }
+    if (key && !strcmp(key, "split")) { g_split = value; g_lem_split = value; return MSMP_OK; }
     msmp::set_error("msmp_tune: unknown key");
     return MSMP_ERR_ARG;
 }

@@ -22,6 +22,13 @@ def mp():
     return msmp_pde_amd
 
 
+@pytest.fixture(autouse=True)
+def _restore_default_matrix_path(mp):
+    """Tests toggle msmp_tune("split"); whatever happens, the next test starts from the library default."""
+    yield
+    mp.lib().msmp_tune(b'split', 1)
+
+
 def dev(a, dtype=None):
     t = torch.as_tensor(np.ascontiguousarray(a))
     if dtype is not None:
@@ -136,6 +143,7 @@ def test_layer_pieces_vs_oracle(mp, tw, nv, sizes, shuffle):
     from msmp_pde_amd._lib import check, ptr, current_stream
     from msmp_pde_amd.graph import GraphStructure
     L = mp.lib()
+    L.msmp_tune(b'split', 0)          # first the fp32-MFMA kernels; the fp16-split editions are toggled below
     rng = np.random.default_rng(hash((tw, nv, len(sizes))) % 2 ** 31)
     ei, batch = random_graph_batch(rng, sizes, shuffle=shuffle)
     n, e = len(batch), ei.shape[1]
@@ -208,7 +216,7 @@ def test_layer_pieces_vs_oracle(mp, tw, nv, sizes, shuffle):
             check(L.msmp_node_update_f32(ptr(dh), ptr(agg), ptr(dvar), n, nv, ptr(blob), mode, ptr(o_), st), 'node split')
             outs_split.append(o_)
     finally:
-        L.msmp_tune(b'split', 0)
+        L.msmp_tune(b'split', 0)      # back to the fp32-MFMA kernels for the remaining piece checks
     relerr = lambda t, ref: np.abs(t.double().cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
     e_split = relerr(agg_s, ref_agg64)
     print(f'agg error vs float64: factorised {e_fact:.2e}, dense {e_dense:.2e}, fp16-split {e_split:.2e};  '
@@ -312,8 +320,14 @@ def test_lem_encoder_kernel(mp, ninp, t_len, n):
     mlp = torch.nn.Sequential(torch.nn.Linear(128, 128), mp.Swish(), torch.nn.Linear(128, 128), mp.Swish()).cuda()
     xin = torch.randn(n, t_len, ninp, device='cuda')
     with torch.no_grad():
-        y = lem.encode(xin, None)
-        h = lem.encode(xin, mlp)
+        ys = lem.encode(xin, None)           # default: fp16-split matrix path
+        hs = lem.encode(xin, mlp)
+        mp.lib().msmp_tune(b'split', 0)
+        try:
+            y = lem.encode(xin, None)        # fp32-MFMA kernel
+            h = lem.encode(xin, mlp)
+        finally:
+            mp.lib().msmp_tune(b'split', 1)
         y_torch = lem(xin.permute(1, 0, 2).contiguous())
     sd = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in lem.state_dict().items()}
     ref_y = O.lem_forward(xin.permute(1, 0, 2).double().cpu().numpy(), sd['rnn.weights'], sd['rnn.weights_lin_z'],
@@ -323,8 +337,10 @@ def test_lem_encoder_kernel(mp, ninp, t_len, n):
     e_y = np.abs(y.double().cpu().numpy() - ref_y).max()
     e_h = np.abs(h.double().cpu().numpy() - ref_h).max()
     e_t = np.abs(y_torch.double().cpu().numpy() - ref_y).max()
-    print(f'lem ninp={ninp} T={t_len}: hip y {e_y:.2e}, hip h {e_h:.2e}, torch-gpu y {e_t:.2e}')
-    assert e_y < 5e-6 and e_h < 5e-6
+    e_ys = np.abs(ys.double().cpu().numpy() - ref_y).max()
+    e_hs = np.abs(hs.double().cpu().numpy() - ref_h).max()
+    print(f'lem ninp={ninp} T={t_len}: hip y {e_y:.2e}, hip h {e_h:.2e}, fp16-split y {e_ys:.2e} h {e_hs:.2e}, torch-gpu y {e_t:.2e}')
+    assert e_y < 5e-6 and e_h < 5e-6 and e_ys < 5e-6 and e_hs < 5e-6
 
 
 def test_fused_aggregate_degree_limits(mp):

@@ -21,6 +21,12 @@ def mp():
     return msmp_pde_amd
 
 
+@pytest.fixture(autouse=True)
+def _restore_default_matrix_path(mp):
+    yield
+    mp.lib().msmp_tune(b'split', 1)
+
+
 def make_pde(mp, exp, d):
     pde_name, eqv, unstructured = EXPERIMENTS[exp]
     kw = dict(tmin=float(d['tmin']), tmax=float(d['tmax']), grid_size=[250, 100])
@@ -50,17 +56,22 @@ def test_solver_golden_forward_and_rollout(mp, kind):
     data = to_data(mp, g)
     from msmp_pde_amd import layers
     with torch.no_grad():
-        out = model(data)
-        layers.DENSE_MESSAGE = True          # the literal per-edge GEMM of message_net_1
+        out = model(data)                    # default: factorised message_net_1, fp16-split matrix path
+        mp.lib().msmp_tune(b'split', 0)
         try:
+            out_f32 = model(data)            # fp32-MFMA kernels
+            layers.DENSE_MESSAGE = True      # + the literal per-edge GEMM of message_net_1
             out_dense = model(data)
         finally:
             layers.DENSE_MESSAGE = False
+            mp.lib().msmp_tune(b'split', 1)
     assert out.dtype == data.x.dtype and out.shape == d['out'].shape
     err = np.abs(out.double().cpu().numpy() - d['out']).max()
+    err_f32 = np.abs(out_f32.double().cpu().numpy() - d['out']).max()
     err_dense = np.abs(out_dense.double().cpu().numpy() - d['out']).max()
-    print(f'{kind}: max|hip - reference| = {err:.3e} (factorised message_net_1), {err_dense:.3e} (dense)')
-    assert err < TOL and err_dense < TOL, (err, err_dense)
+    print(f'{kind}: max|hip - reference| = {err:.3e} (default: factorised + fp16-split), {err_f32:.3e} (fp32 MFMA), '
+          f'{err_dense:.3e} (fp32 MFMA, dense message_net_1)')
+    assert err < TOL and err_f32 < TOL and err_dense < TOL, (err, err_f32, err_dense)
 
     n_roll = int(d['n_roll'])
     if n_roll:      # experiments/train_helper.py:255-261 through the GraphCreator mirror
@@ -105,7 +116,8 @@ def test_full_depth_vs_oracle(mp, kind, exp):
     # run in float32.  The HIP path must be inside 1e-5 wherever float32 can be, and never worse than
     # 8x the float32 floor (max-abs over ~1e5 outputs is an outlier statistic; DESIGN.md "Numerics").
     floor = np.abs(O.solver_forward(kind, sd, g, case.pde, TW, case.eqv, 6, dtype=np.float32).astype(np.float64) - ref).max()
-    print(f'{kind}/{exp}: depth 6, max|hip - oracle| = {err:.3e}, float32-oracle floor = {floor:.3e}')
+    rms = np.sqrt(np.mean((out.double().cpu().numpy() - ref) ** 2))
+    print(f'{kind}/{exp}: depth 6, max|hip - oracle| = {err:.3e} (rms {rms:.2e}), float32-oracle floor = {floor:.3e}')
     assert err < max(TOL, 8 * floor), (err, floor)
 
 
