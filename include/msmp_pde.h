@@ -148,26 +148,28 @@ int msmp_node_update_f32(const float* h, const float* agg, const float* vars, in
 
 /* L4  torch_geometric.nn.InstanceNorm(128) (affine=False, no running stats), experiments/models_gnn.py:
  * 59,66,122,129: per graph g and channel (x-mean)/sqrt(biased var + eps). */
-int msmp_instance_norm_f32(const float* x, const int32_t* graph_ptr, int64_t n_graphs, float eps,
-                           float* out, msmp_stream_t stream);
+/* max_graph_nodes = size of the largest graph (0 if unknown): up to 128 nodes the rows of a graph are read once
+ * and kept in registers across the three passes; larger graphs use the generic kernels (same results). */
+int msmp_instance_norm_f32(const float* x, const int32_t* graph_ptr, int64_t n_graphs,
+                           int max_graph_nodes, float eps, float* out, msmp_stream_t stream);
 
 /* L4+L5  gate blend, experiments/models_gnn.py:1204-1207 / 1365-1368 (models_gnn2D.py:267-269, 438-441):
  *   tau = sigmoid(InstanceNorm(gate_pre));  out = (1-tau)*h + tau*Swish(InstanceNorm(main_pre)). */
 int msmp_gate_blend_f32(const float* h, const float* gate_pre, const float* main_pre,
-                        const int32_t* graph_ptr, int64_t n_graphs, float eps, float* out,
-                        msmp_stream_t stream);
+                        const int32_t* graph_ptr, int64_t n_graphs, int max_graph_nodes, float eps,
+                        float* out, msmp_stream_t stream);
 
 /* One whole message-passing layer: GNN_Layer.forward / GNN_LayerLin.forward
  * (experiments/models_gnn.py:61-67 / 124-130) = L1 -> L2 -> L3 -> L4; when packed_gate != NULL the
  * gated pair of one iteration of the solver loop (L5) is evaluated and blended.  h_out may not alias h.
  * max_in_degree = largest CSR row length (pass -1 if unknown): when <= 256 the fused L1+L2 kernel is
- * used, otherwise the message tensor goes through the workspace.  Workspace size from
- * msmp_mp_layer_workspace_bytes (same max_in_degree). */
+ * used, otherwise the message tensor goes through the workspace; max_graph_nodes as in
+ * msmp_instance_norm_f32.  Workspace size from msmp_mp_layer_workspace_bytes (same max_in_degree). */
 size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges, int gated, int max_in_degree);
 int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars,
                       const int32_t* rowptr, const int32_t* col, const int32_t* tgt,
                       const int32_t* graph_ptr, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
-                      int max_in_degree, int tw, int nv, const float* packed_main,
+                      int max_in_degree, int max_graph_nodes, int tw, int nv, const float* packed_main,
                       const float* packed_gate, int mode,
                       float eps, float* h_out, void* workspace, size_t workspace_bytes,
                       msmp_stream_t stream);

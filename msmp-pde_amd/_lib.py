@@ -28,13 +28,13 @@ SIGNATURES = {
     'msmp_edge_mlp_f32': (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'msmp_scatter_mean_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'msmp_node_update_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
-    'msmp_instance_norm_f32': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
-    'msmp_gate_blend_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    'msmp_instance_norm_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
+    'msmp_gate_blend_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
     'msmp_edge_aggregate_f32': (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'msmp_node_project_f32': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'msmp_edge_aggregate_projected_f32': (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'msmp_mp_layer_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int, c_int]),
-    'msmp_mp_layer_f32': (c_int, [c_void_p] * 8 + [c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+    'msmp_mp_layer_f32': (c_int, [c_void_p] * 8 + [c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                                    c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     'msmp_packed_lem_floats': (c_int64, []),
     'msmp_pack_lem_f32': (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p]),

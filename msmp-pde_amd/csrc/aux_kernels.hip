@@ -248,6 +248,90 @@ __global__ __launch_bounds__(256) void gate_blend_kernel(const float* __restrict
     }
 }
 
+// Register-resident editions for graphs of at most 8*RPT nodes (E2: 100 -> RPT = 13): every row of the graph is
+// read from HBM ONCE and kept in registers across the mean pass, the centred-variance pass and the apply pass
+// (the generic kernels above re-read it three times: with 2048 graphs in flight the rows do not survive in L2).
+// Same arithmetic in the same order (results agree with the generic kernels to the last bit or two: the compiler
+// contracts the two loop forms differently).
+template <int RPT>
+__device__ __forceinline__ void stats_from_regs(const f32x4 (&v)[RPT], int cnt, int n_rows, int cg, int rs, f32x4* red, float eps,
+                                                f32x4& mean, f32x4& rstd) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+        if (i < cnt) s += v[i];
+    const float inv = 1.0f / (float)max(n_rows, 1);
+    mean = block_colsum(s, red, cg, rs) * inv;
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+        if (i < cnt) {
+            const f32x4 d = v[i] - mean;
+            q += d * d;
+        }
+    const f32x4 var = block_colsum(q, red, cg, rs) * inv;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) rstd[m] = 1.0f / sqrtf(var[m] + eps);
+}
+
+template <int RPT>
+__global__ __launch_bounds__(256) void gate_blend_reg_kernel(const float* __restrict__ h, const float* __restrict__ gate,
+                                                             const float* __restrict__ mainp, const int* __restrict__ graph_ptr,
+                                                             float eps, float* __restrict__ out) {
+    __shared__ f32x4 red[256];
+    const int cg = threadIdx.x & 31, rs = threadIdx.x >> 5;
+    const int n0 = graph_ptr[blockIdx.x], n1 = graph_ptr[blockIdx.x + 1];
+    const int cnt = (n1 - n0 - rs + 7) / 8;              // rows n0 + rs + 8 i, i < cnt
+    const f32x4* gp = reinterpret_cast<const f32x4*>(gate);
+    const f32x4* mp = reinterpret_cast<const f32x4*>(mainp);
+    f32x4 gv[RPT], mv[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+        if (i < cnt) {
+            const size_t o = (size_t)(n0 + rs + 8 * i) * (H / 4) + cg;
+            gv[i] = gp[o];
+            mv[i] = mp[o];
+        }
+    f32x4 gm, gr, mm, mr;
+    stats_from_regs<RPT>(gv, cnt, n1 - n0, cg, rs, red, eps, gm, gr);
+    stats_from_regs<RPT>(mv, cnt, n1 - n0, cg, rs, red, eps, mm, mr);
+    const f32x4* hp = reinterpret_cast<const f32x4*>(h);
+    f32x4* op = reinterpret_cast<f32x4*>(out);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+        if (i < cnt) {
+            const size_t o = (size_t)(n0 + rs + 8 * i) * (H / 4) + cg;
+            const f32x4 g = (gv[i] - gm) * gr, mnv = (mv[i] - mm) * mr, hv = hp[o];
+            f32x4 res;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float tau = sigmoidf_(g[m]);
+                res[m] = (1.0f - tau) * hv[m] + tau * swishf(mnv[m]);
+            }
+            op[o] = res;
+        }
+}
+
+template <int RPT>
+__global__ __launch_bounds__(256) void instance_norm_reg_kernel(const float* __restrict__ x, const int* __restrict__ graph_ptr,
+                                                                float eps, float* __restrict__ out) {
+    __shared__ f32x4 red[256];
+    const int cg = threadIdx.x & 31, rs = threadIdx.x >> 5;
+    const int n0 = graph_ptr[blockIdx.x], n1 = graph_ptr[blockIdx.x + 1];
+    const int cnt = (n1 - n0 - rs + 7) / 8;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x);
+    f32x4 v[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+        if (i < cnt) v[i] = xp[(size_t)(n0 + rs + 8 * i) * (H / 4) + cg];
+    f32x4 mean, rstd;
+    stats_from_regs<RPT>(v, cnt, n1 - n0, cg, rs, red, eps, mean, rstd);
+    f32x4* op = reinterpret_cast<f32x4*>(out);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+        if (i < cnt) op[(size_t)(n0 + rs + 8 * i) * (H / 4) + cg] = (v[i] - mean) * rstd;
+}
+
 }  // namespace msmp
 
 using namespace msmp;
@@ -311,21 +395,38 @@ extern "C" int msmp_scatter_mean_f32(const float* msg, const int32_t* rowptr, in
     return check_launch("scatter_mean_kernel");
 }
 
-extern "C" int msmp_instance_norm_f32(const float* x, const int32_t* graph_ptr, int64_t n_graphs, float eps, float* out,
-                                      msmp_stream_t stream) {
+// largest graph (nodes) the register-resident norm kernels are built for: 8 row slices x 16 rows per thread
+static const int kRegNormMaxNodes = 128;
+
+extern "C" int msmp_instance_norm_f32(const float* x, const int32_t* graph_ptr, int64_t n_graphs, int max_graph_nodes, float eps,
+                                      float* out, msmp_stream_t stream) {
+    const int g_max_graph_nodes = max_graph_nodes;
     MSMP_REQUIRE(x && graph_ptr && out, MSMP_ERR_ARG, "msmp_instance_norm_f32: null pointer");
     MSMP_REQUIRE(n_graphs > 0 && n_graphs < (1L << 31), MSMP_ERR_ARG, "msmp_instance_norm_f32: bad n_graphs");
     timing_begin(MSMP_K_NORM, (hipStream_t)stream);
+    if (g_max_graph_nodes > 0 && g_max_graph_nodes <= 104)
+        hipLaunchKernelGGL(instance_norm_reg_kernel<13>, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, x, graph_ptr, eps, out);
+    else if (g_max_graph_nodes > 0 && g_max_graph_nodes <= kRegNormMaxNodes)
+        hipLaunchKernelGGL(instance_norm_reg_kernel<16>, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, x, graph_ptr, eps, out);
+    else
     hipLaunchKernelGGL(instance_norm_kernel, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, x, graph_ptr, eps, out);
     timing_end(MSMP_K_NORM, (hipStream_t)stream);
     return check_launch("instance_norm_kernel");
 }
 
 extern "C" int msmp_gate_blend_f32(const float* h, const float* gate_pre, const float* main_pre, const int32_t* graph_ptr,
-                                   int64_t n_graphs, float eps, float* out, msmp_stream_t stream) {
+                                   int64_t n_graphs, int max_graph_nodes, float eps, float* out, msmp_stream_t stream) {
+    const int g_max_graph_nodes = max_graph_nodes;
     MSMP_REQUIRE(h && gate_pre && main_pre && graph_ptr && out, MSMP_ERR_ARG, "msmp_gate_blend_f32: null pointer");
     MSMP_REQUIRE(n_graphs > 0 && n_graphs < (1L << 31), MSMP_ERR_ARG, "msmp_gate_blend_f32: bad n_graphs");
     timing_begin(MSMP_K_NORM, (hipStream_t)stream);
+    if (g_max_graph_nodes > 0 && g_max_graph_nodes <= 104)
+        hipLaunchKernelGGL(gate_blend_reg_kernel<13>, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, h, gate_pre,
+                           main_pre, graph_ptr, eps, out);
+    else if (g_max_graph_nodes > 0 && g_max_graph_nodes <= kRegNormMaxNodes)
+        hipLaunchKernelGGL(gate_blend_reg_kernel<16>, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, h, gate_pre,
+                           main_pre, graph_ptr, eps, out);
+    else
     hipLaunchKernelGGL(gate_blend_kernel, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, h, gate_pre, main_pre,
                        graph_ptr, eps, out);
     timing_end(MSMP_K_NORM, (hipStream_t)stream);
@@ -346,8 +447,8 @@ extern "C" size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges
 
 extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars,
                                  const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const int32_t* graph_ptr,
-                                 int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int max_in_degree, int tw, int nv,
-                                 const float* packed_main, const float* packed_gate, int mode, float eps, float* h_out,
+                                 int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int max_in_degree, int max_graph_nodes,
+                                 int tw, int nv, const float* packed_main, const float* packed_gate, int mode, float eps, float* h_out,
                                  void* workspace, size_t workspace_bytes, msmp_stream_t stream) {
     MSMP_REQUIRE(h && u && pos && vars && rowptr && col && tgt && graph_ptr && packed_main && h_out && workspace,
                  MSMP_ERR_ARG, "msmp_mp_layer_f32: null pointer");
@@ -388,6 +489,6 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
     }
     if ((rc = aggregate(packed_main))) return rc;
     if ((rc = msmp_node_update_f32(h, agg, vars, n_nodes, nv, packed_main, mode, pre_main, stream))) return rc;
-    if (gated) return msmp_gate_blend_f32(h, pre_gate, pre_main, graph_ptr, n_graphs, eps, h_out, stream);
-    return msmp_instance_norm_f32(pre_main, graph_ptr, n_graphs, eps, h_out, stream);
+    if (gated) return msmp_gate_blend_f32(h, pre_gate, pre_main, graph_ptr, n_graphs, max_graph_nodes, eps, h_out, stream);
+    return msmp_instance_norm_f32(pre_main, graph_ptr, n_graphs, max_graph_nodes, eps, h_out, stream);
 }

@@ -55,6 +55,7 @@ class GraphStructure(object):
         self.n_graphs = int(counts.numel())
         self.graph_ptr = torch.zeros(self.n_graphs + 1, dtype=torch.int32, device=dev)
         self.graph_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        self.max_graph_nodes = int(counts.max().item()) if counts.numel() else 0
         self.rowptr = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
         self.col = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
         self.tgt = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)

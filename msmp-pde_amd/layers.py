@@ -124,7 +124,8 @@ def _mp_layer_hip(h, u, pos_x, variables, gs, main, gate, eps, dense_message=Non
     ws_bytes = L.msmp_mp_layer_workspace_bytes(n, gs.n_edges, int(gated), gs.max_in_degree)
     ws = _Workspace.get(ws_bytes, h.device)
     check(L.msmp_mp_layer_f32(ptr(h), ptr(u), ptr(pos_x), ptr(variables), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt),
-                              ptr(gs.graph_ptr), n, gs.n_edges, gs.n_graphs, gs.max_in_degree, main.time_window, main.n_variables,
+                              ptr(gs.graph_ptr), n, gs.n_edges, gs.n_graphs, gs.max_in_degree, gs.max_graph_nodes, main.time_window,
+                              main.n_variables,
                               ptr(main.packed()), ptr(gate.packed()) if gated else None, mode, eps, ptr(out),
                               ptr(ws), ws.numel(), current_stream()), 'msmp_mp_layer_f32')
     return out

@@ -44,7 +44,7 @@ def test_argument_errors_are_reported_not_thrown(mp):
     L = mp.lib()
     rc = L.msmp_scatter_mean_f32(None, None, 10, None, None)
     assert rc == -1 and b'null pointer' in L.msmp_last_error()
-    rc = L.msmp_mp_layer_f32(*([None] * 8), 1, 1, 1, 6, 25, 2, None, None, 0, 1e-5, None, None, 0, None)
+    rc = L.msmp_mp_layer_f32(*([None] * 8), 1, 1, 1, 6, 100, 25, 2, None, None, 0, 1e-5, None, None, 0, None)
     assert rc == -1
 
 
