@@ -475,16 +475,56 @@ __global__ __launch_bounds__(256) void node_update_kernel(NodeArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// fp16-split editions of the two node kernels (mfma_tiles.h).  B fragments in natural k order: lane (n, h)
-// takes the 8 consecutive features 16s + 8h .. +7 of each K = 16 step (two 16-B loads of the node row).
+// fp16-split editions of the two node kernels (mfma_tiles.h).
+// B operand: the workgroup's 128 node rows are read COALESCED (8 threads x 16 B = one 128-B line per node and
+// 32-channel chunk), split into hi/lo fp16 by the loading thread and staged in LDS as
+//   [node 128][hi 32 halfs | lo 32 halfs] (+16 B pad: row stride 144 B = 36 dwords -> conflict-free ds_read_b128),
+// double buffered beside the weight chunks; lane (n, h) then reads its four fragments (hi/lo x two K=16 steps,
+// natural k order) with 16-B LDS reads.  (Letting every lane fetch its own 512-B row straight from memory touches
+// each cache line four times with 32-B pieces: measured, that row gather was 34 % of the kernel.)
 // ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ void gather_split_row(const float* __restrict__ row32, int hh, half8 (&bhi)[1][2], half8 (&blo)[1][2]) {
+constexpr int BROW = 72;                         // halfs per staged node row (64 used)
+constexpr int BTILE_FLOATS = 128 * BROW / 2;     // one staged B tile in floats (18 KB)
+
+struct BStage {
+    f32x4 r[4];
+};
+
+// thread t covers (node = (t + 256 i) >> 3, 4 channels at 4 ((t + 256 i) & 7)) for i = 0..3
+__device__ __forceinline__ void bstage_load(BStage& b, const float* __restrict__ src, long n0, long n_nodes, int ch32, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        long node = n0 + (idx >> 3);
+        node = node < n_nodes ? node : n_nodes - 1;
+        b.r[i] = *reinterpret_cast<const f32x4*>(src + (size_t)node * H + ch32 + 4 * (idx & 7));
+    }
+}
+
+__device__ __forceinline__ void bstage_store(const BStage& b, _Float16* tile, int tid) {
+    using half4 = __attribute__((ext_vector_type(4))) _Float16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        half4 hi, lo;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const _Float16 h = (_Float16)b.r[i][m];
+            hi[m] = h;
+            lo[m] = (_Float16)(b.r[i][m] - (float)h);
+        }
+        _Float16* row = tile + (idx >> 3) * BROW + 4 * (idx & 7);
+        *reinterpret_cast<half4*>(row) = hi;
+        *reinterpret_cast<half4*>(row + 32) = lo;
+    }
+}
+
+__device__ __forceinline__ void bfrag_read(const _Float16* tile, int node_local, int hh, half8 (&bhi)[1][2], half8 (&blo)[1][2]) {
+    const _Float16* row = tile + node_local * BROW + 8 * hh;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(row32 + 16 * s + 8 * hh);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(row32 + 16 * s + 8 * hh + 4);
-        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        split8(v, bhi[0][s], blo[0][s]);
+        bhi[0][s] = *reinterpret_cast<const half8*>(row + 16 * s);
+        blo[0][s] = *reinterpret_cast<const half8*>(row + 32 + 16 * s);
     }
 }
 
@@ -495,31 +535,44 @@ struct ProjSplitArgs {
 };
 
 __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs sa) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS + 2 * BTILE_FLOATS];
+    float* wbuf = lds;
+    _Float16* bbuf = reinterpret_cast<_Float16*>(lds + 2 * SPLIT_CHUNK_FLOATS);
     const ProjArgs& a = sa.b;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
-    const long n = (long)blockIdx.x * 128 + wave * 32 + c;
+    const long n0 = (long)blockIdx.x * 128;
+    const long n = n0 + wave * 32 + c;
     const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
+    const int nl = wave * 32 + c;
     const float sc = sa.scales[0], inv = sa.scales[4];
 
     f32x16 p[4][1], qa[4][1];
     acc_init_bias_scaled<1>(a.b1, sc, hh, p);
     acc_zero<1>(qa);
+    // step st = 0..7 uses weight chunk (st & 1 ? 4 : 0) + (st >> 1) (P then Q of the same h chunk st >> 1)
     WStage ws;
+    BStage bs;
     wstage_load(ws, sa.w1s, tid);
-    wstage_store_linear(ws, lds, tid);
+    bstage_load(bs, a.h, n0, a.n_nodes, 0, tid);
+    wstage_store_linear(ws, wbuf, tid);
+    bstage_store(bs, bbuf, tid);
     __syncthreads();
-    const float* hp = a.h + (size_t)nc * H;
-    for (int ch = 0; ch < 8; ++ch) {
-        wstage_load(ws, sa.w1s + (size_t)(ch + 1) * SPLIT_CHUNK_FLOATS, tid);
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        const int nxt = st + 1;                                   // next step's weight chunk (8 = first tail chunk)
+        const int nchunk = nxt < 8 ? ((nxt & 1) ? 4 : 0) + (nxt >> 1) : 8;
+        wstage_load(ws, sa.w1s + (size_t)nchunk * SPLIT_CHUNK_FLOATS, tid);
+        if ((st & 1) && st < 7) bstage_load(bs, a.h, n0, a.n_nodes, 32 * ((st >> 1) + 1), tid);
         half8 bhi[1][2], blo[1][2];
-        gather_split_row(hp + 32 * (ch & 3), hh, bhi, blo);
-        if (ch < 4) mma_chunk_split<1>(lds + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, p);
-        else mma_chunk_split<1>(lds + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, qa);
-        wstage_store_linear(ws, lds + ((ch + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+        bfrag_read(bbuf + ((st >> 1) & 1) * 128 * BROW, nl, hh, bhi, blo);
+        if (st & 1) mma_chunk_split<1>(wbuf + (st & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, qa);
+        else mma_chunk_split<1>(wbuf + (st & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, p);
+        wstage_store_linear(ws, wbuf + ((st + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+        if ((st & 1) && st < 7) bstage_store(bs, bbuf + (((st >> 1) + 1) & 1) * 128 * BROW, tid);
         __syncthreads();
     }
+    // tail chunks 8.. : [u_n, p_n, v_n] for P and [-u_n, -p_n, 0] for Q (per-lane scalar loads; 1-2 chunks)
     const float* un = a.u + (size_t)nc * a.tw;
     for (int ch = 8; ch < a.nc1; ++ch) {
         if (ch + 1 < a.nc1) wstage_load(ws, sa.w1s + (size_t)(ch + 1) * SPLIT_CHUNK_FLOATS, tid);
@@ -540,9 +593,9 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs s
             split8(vp, phi[0][s], plo[0][s]);
             split8(vq, qhi[0][s], qlo[0][s]);
         }
-        mma_chunk_split<1>(lds + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, phi, plo, p);
-        mma_chunk_split<1>(lds + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, qhi, qlo, qa);
-        if (ch + 1 < a.nc1) wstage_store_linear(ws, lds + ((ch + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+        mma_chunk_split<1>(wbuf + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, phi, plo, p);
+        mma_chunk_split<1>(wbuf + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, qhi, qlo, qa);
+        if (ch + 1 < a.nc1) wstage_store_linear(ws, wbuf + ((ch + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
         __syncthreads();
     }
     if (n < a.n_nodes) {
@@ -558,6 +611,18 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs s
                 *reinterpret_cast<f32x4*>(po + 32 * T + 8 * q) = v;
                 *reinterpret_cast<f32x4*>(qo + 32 * T + 8 * q) = w;
             }
+    }
+}
+
+// node_update keeps the per-lane row gather: with 50 KB less LDS three workgroups share a CU, which measured
+// faster (1.28 vs 1.39 ms per step) than the coalesced staging that pays off in node_proj (1.34 vs 1.46).
+__device__ __forceinline__ void gather_split_row(const float* __restrict__ row32, int hh, half8 (&bhi)[1][2], half8 (&blo)[1][2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(row32 + 16 * s + 8 * hh);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(row32 + 16 * s + 8 * hh + 4);
+        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        split8(v, bhi[0][s], blo[0][s]);
     }
 }
 
