@@ -758,6 +758,7 @@ static int g_edge_nb = 0;    // tuning override (msmp_tune): 0 = automatic, 1 / 
 
 extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
+    if (key && !strcmp(key, "lem")) { g_lem_split = value; return MSMP_OK; }
     if (key && !strcmp(key, "split")) { g_split = value; g_lem_split = value; return MSMP_OK; }
     msmp::set_error("msmp_tune: unknown key");
     return MSMP_ERR_ARG;
