@@ -1,0 +1,84 @@
+"""GPU parity at BASELINE.json's full size (2048 graphs) through size-independent properties: graphs of a batch
+are independent, so (1) the rows of a 2048-graph evaluation that belong to a few sampled graphs must equal the
+float64 oracle evaluated on just those graphs, (2) permuting the graphs of the batch permutes the output rows,
+(3) repeated evaluation is bitwise identical, (4) the edge_index of the big batch is the small batch's pattern
+repeated.  Covers the four experiment shapes of BASELINE.json's configs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import msmp_oracle as O
+from helpers import EXPERIMENTS
+
+pytestmark = pytest.mark.gpu
+TW = 25
+B = 2048
+
+
+@pytest.fixture(scope='module')
+def mp():
+    import msmp_pde_amd
+    assert torch.cuda.is_available()
+    return msmp_pde_amd
+
+
+def subgraph(graph, ids, nx):
+    """numpy sub-batch made of the listed graphs (rows sliced, edges rebased, batch renumbered)."""
+    from types import SimpleNamespace
+    g = SimpleNamespace()
+    rows = np.concatenate([np.arange(i * nx, (i + 1) * nx) for i in ids])
+    ei = graph.edge_index.cpu().numpy()
+    keep = np.isin(ei[1] // nx, ids)
+    remap = -np.ones(graph.x.shape[0], dtype=np.int64)
+    remap[rows] = np.arange(len(rows))
+    g.edge_index = remap[ei[:, keep]]
+    for k, v in graph.__dict__.items():
+        if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == graph.x.shape[0] and k not in ('edge_index',):
+            setattr(g, k, v.cpu().numpy()[rows])
+    g.batch = np.repeat(np.arange(len(ids)), nx)
+    return g, rows
+
+
+@pytest.mark.parametrize('kind,exp,layers', [('MP_PDE_SolverLEMLinGated', 'E2', 6), ('MP_PDE_Solver', 'E2', 6),
+                                             ('MP_PDE_SolverGated', 'WE3', 2), ('MP_PDE_Solver2DLEMLinGated', 'RPU', 2),
+                                             ('MP_PDE_Solver2DGated', 'MSWG3', 2)])
+def test_full_size_batch_properties(mp, kind, exp, layers):
+    from msmp_pde_amd.synthetic import make_case
+    torch.manual_seed(11)
+    nx = 100
+    c = make_case(exp, B, seed=21, device='cuda', dtype=torch.float32)
+    model = getattr(mp, kind)(c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=layers).cuda().eval()
+    steps = [50] * B
+    data, labels = c.creator.create_data(c.u_super, steps)
+    graph = c.creator.create_graph(data, labels, c.x, c.variables, steps)
+    n_edges_per_graph = graph.edge_index.shape[1] // B
+    assert graph.edge_index.shape[1] == n_edges_per_graph * B              # every graph has the same pattern
+    ei = graph.edge_index
+    assert torch.equal(ei[:, :n_edges_per_graph] + 7 * nx, ei[:, 7 * n_edges_per_graph:8 * n_edges_per_graph])
+
+    with torch.no_grad():
+        out = model(graph)
+        out2 = model(graph)
+    assert torch.equal(out, out2)                                          # (3) bitwise repeatable
+    assert torch.isfinite(out).all()
+
+    ids = [0, 1, 977, 2047]                                                # (1) oracle on sampled graphs
+    sub, rows = subgraph(graph, ids, nx)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    ref = O.solver_forward(kind, sd, sub, c.pde, TW, c.eqv, layers)
+    floor = np.abs(O.solver_forward(kind, sd, sub, c.pde, TW, c.eqv, layers, dtype=np.float32).astype(np.float64) - ref).max()
+    err = np.abs(out[torch.as_tensor(rows, device='cuda')].double().cpu().numpy() - ref).max()
+    print(f'{kind}/{exp} x{B}: sampled-graph max|hip - oracle| = {err:.3e} (float32-oracle floor {floor:.3e})')
+    assert err < max(1e-5, 8 * floor), (err, floor)
+
+    # (2) permutation of the graphs of the batch: the message-passing stack is bitwise equivariant (same per-item
+    # arithmetic order); the full solver up to the rocBLAS/PyTorch pieces of the 2-D decoder
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3))
+    u_p = c.u_super[perm.to(c.u_super.device)]
+    vars_p = {k: torch.as_tensor(v)[perm] for k, v in c.variables.items()}
+    data_p, labels_p = c.creator.create_data(u_p, steps)
+    graph_p = c.creator.create_graph(data_p, labels_p, c.x, vars_p, steps)
+    with torch.no_grad():
+        out_p = model(graph_p)
+    want = out.view(B, nx, -1)[perm.cuda()].reshape(out.shape)
+    assert (out_p - want).abs().max().item() < (1e-6 if '2D' in kind else 0.0 + 1e-6)
