@@ -220,31 +220,58 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
             }
         }
     } else {
-        // Mean over the in-edges of each target, one 32-channel tile at a time:
-        // stage [128*NB local edges][32 ch] (row stride LDW) in the weight buffers, then thread
-        // (slot = tid >> 3, cq = tid & 7) sums the rows of node tile_n0 + slot (+32, ...) for channels 4cq..4cq+3.
-        const int cq = tid & 7, slot = tid >> 3;
+        // Mean over the in-edges of each target.  The messages are staged through LDS (re-using the weight buffers)
+        // CPR channels at a time as [local edge][CPR] (row stride CPR + 4), then thread (slot, cq) sums the rows of
+        // node tile_n0 + slot (+ NSLOT, ...) for channels 4cq..4cq+3 in CSR order.  128-edge tiles stage 64 channels per
+        // round (2 rounds, 4 barriers), 256-edge tiles 32 (4 rounds).  The CSR row bounds are fetched once, up front.
+        constexpr int TPR = NB == 1 ? 2 : 1;              // 32-channel tiles per round
+        constexpr int CPR = 32 * TPR, LDR = CPR + 4;      // channels per round, LDS row stride (dwords; 4*odd)
+        constexpr int NCQ = CPR / 4, NSLOT = 256 / NCQ;
+        const int cq = tid & (NCQ - 1), slot = tid / NCQ;
+        int r0a[4], r1a[4];
 #pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            __syncthreads();     // previous readers of lds (W2 chunk 3 / previous tile) are done
+        for (int k = 0; k < 4; ++k) {
+            const int node = tile_n0 + slot + k * NSLOT;
+            const bool in = node < tile_n1;
+            r0a[k] = in ? a.rowptr[node] - (int)tile_e0 : 0;
+            r1a[k] = in ? a.rowptr[node + 1] - (int)tile_e0 : 0;
+        }
+#pragma unroll
+        for (int R = 0; R < 4 / TPR; ++R) {
+            __syncthreads();     // previous readers of lds (W2 chunk 3 / previous round) are done
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                float* o = lds + (wave * 32 * NB + 32 * nb + c) * LDW + 4 * hh;
+                float* o = lds + (wave * 32 * NB + 32 * nb + c) * LDR + 4 * hh;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v;
+                for (int tt = 0; tt < TPR; ++tt)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) v[m] = swishf(y[T][nb][4 * q + m]);
-                    *reinterpret_cast<f32x4*>(o + 8 * q) = v;
-                }
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) v[m] = swishf(y[R * TPR + tt][nb][4 * q + m]);
+                        *reinterpret_cast<f32x4*>(o + 32 * tt + 8 * q) = v;
+                    }
             }
             __syncthreads();
-            for (int node = tile_n0 + slot; node < tile_n1; node += 32) {
-                const int r0 = a.rowptr[node] - (int)tile_e0, r1 = a.rowptr[node + 1] - (int)tile_e0;
+            int k = 0;
+            for (int node = tile_n0 + slot; node < tile_n1; node += NSLOT, ++k) {
+                int r0, r1;
+                if (k < 4) { r0 = r0a[k < 4 ? k : 0]; r1 = r1a[k < 4 ? k : 0]; }
+                else { r0 = a.rowptr[node] - (int)tile_e0; r1 = a.rowptr[node + 1] - (int)tile_e0; }
+                // rows are fetched four at a time (independent LDS reads in flight) and added in CSR order; rows past the
+                // end contribute an exact +0, so the result equals the sequential sum bit for bit
                 f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-                for (int r = r0; r < r1; ++r) sum += *reinterpret_cast<const f32x4*>(lds + r * LDW + 4 * cq);
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                for (int r = r0; r < r1; r += 4) {
+                    f32x4 v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        v[i] = r + i < r1 ? *reinterpret_cast<const f32x4*>(lds + (r + i) * LDR + 4 * cq) : zero;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sum += v[i];
+                }
                 const float inv = 1.0f / (float)max(r1 - r0, 1);
-                *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + 32 * T + 4 * cq) = sum * inv;
+                *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + CPR * R + 4 * cq) = sum * inv;
             }
         }
     }
