@@ -151,8 +151,8 @@ def main():
 
     if rank != 0:
         return
-    tw, nv = 25, len(eqv) + 1
-    k_msg = 2 * H + tw + 1 + nv
+    nv = len(eqv) + 1
+    k_msg = model.gnn_layers[0].message_net_1[0].in_features        # 2H + Tw + 1 + nv (Tw = 2*tw for the *2D classes)
     # Row L1 (message MLP) in the reference's dense formulation: 2*E*K_msg*H + 2*E*H*H per layer.
     flop_l1_dense = 2.0 * n_edges * k_msg * H + 2.0 * n_edges * H * H
     # What the dominant kernel executes in the factorised form: message_net_2 only (message_net_1 became the
@@ -179,7 +179,8 @@ def main():
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{exp} {args.model} ({kind}), {bsz} graphs/GPU x nx=100, time_window=25, '
-                               f'6 gated layer pairs, radius graph n=3', 'graphs_per_gpu': bsz, 'nodes': n_nodes,
+                               f'{"6 gated layer pairs" if model.GATED else "6 layers"}, '
+                               f'{"radius graph n=3" if exp in ("E2", "MSWG3") else "knn graph k=3"}', 'graphs_per_gpu': bsz, 'nodes': n_nodes,
                    'edges': n_edges, 'parallelism': f'dp{world} (graph-sharded, no collective in the rollout)',
                    'graph_steps_per_s': total_steps * bsz / elapsed, 'output_finite': finite},
         # `achieved` counts the fp32 GEMM FLOPs the dominant kernel computes (conservative: the factorised form
@@ -214,7 +215,7 @@ def main():
             sc_bytes = n_edges * H * 4 + n_edges * 0 + (n_nodes + 1) * 4 + n_nodes * H * 4
             out['scatter_hbm'] = {'achieved_GBps': sc_bytes / (ms_sc / n_sc * 1e-3) / 1e9, 'peak_GBps': 8000.0,
                                   'algorithmic_bytes_per_launch': sc_bytes}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         out['cpu_baseline'] = cpu_baseline(args, kind, eqv)
     print(json.dumps(out), flush=True)
 
