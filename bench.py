@@ -170,7 +170,8 @@ def main():
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')     # HBM bytes per launch from the rocprofv3 PMC passes
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get('edge_mlp_kernel', {}).get('hbm_bytes_per_launch')
+            tj = json.load(open(tpath))
+            traffic = (tj.get('edge_mlp_kernel_occ2') or tj.get('edge_mlp_kernel') or {}).get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
     out = {
