@@ -23,6 +23,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with hidden visibility and -Bsymbolic: only the msmp_* entry points are exported, and its
+ * internal (rocPRIM, C++ runtime template) symbols can neither be interposed by nor leak into the host process
+ * (PyTorch ships its own rocPRIM build). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -228,5 +235,8 @@ int msmp_timing_read(int kernel, int64_t* launches_out, double* total_ms_out);
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif /* MSMP_PDE_H */

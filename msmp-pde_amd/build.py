@@ -17,6 +17,7 @@ SOURCES = {  # file -> extra flags
     'graph_kernels.hip': ['-ffp-contract=off'],   # float64 distance compares must round like the host's
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
+          '-fvisibility=hidden', '-fvisibility-inlines-hidden',
           '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
 
 
@@ -42,7 +43,8 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
         objs.append(o)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        # -Bsymbolic: the library's own references (rocPRIM templates, ...) bind to its own definitions
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,-Bsymbolic', '-Wl,--exclude-libs,ALL', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -113,7 +113,14 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
     f32x16 z[4][NB];
     WStage ws;
     int par;                     // LDS buffer holding W2 chunk 0
-    if (FACT) {
+    if (FACT && SPLIT) {
+        // lazy form: the P/Q pieces of channel tile t are gathered one chunk ahead inside the GEMM2 loop below, so the
+        // 64 registers of the whole Swish(P_i + Q_j) row are never live at once (more workgroups per CU)
+        wstage_load(ws, a.w2s, tid);
+        wstage_store_linear(ws, lds, tid);
+        __syncthreads();
+        par = 0;
+    } else if (FACT) {
         wstage_load(ws, SPLIT ? a.w2s : a.w2, tid);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -171,11 +178,33 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
     f32x16 y[4][NB];
     if (SPLIT) {
         acc_init_bias_scaled<NB>(a.b2, a.scales[1], hh, y);
+        f32x4 pq[NB][8];                 // P (0..3) and Q (4..7) pieces of one 32-channel tile: channels 8q + 4hh .. +3
+        auto gather_tile = [&](int t) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float* pp = a.P + (size_t)ni[nb] * H + 32 * t + 4 * hh;
+                const float* qp = a.Q + (size_t)nj[nb] * H + 32 * t + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pq[nb][q] = *reinterpret_cast<const f32x4*>(pp + 8 * q);
+                    pq[nb][4 + q] = *reinterpret_cast<const f32x4*>(qp + 8 * q);
+                }
+            }
+        };
+        gather_tile(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (t < 3) wstage_load(ws, a.w2s + (size_t)(t + 1) * SPLIT_CHUNK_FLOATS, tid);
+            f32x16 zt[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) zt[nb][4 * q + m] = swishf(pq[nb][q][m] + pq[nb][4 + q][m]);
+            if (t < 3) gather_tile(t + 1);          // in flight during this chunk's matrix work
             half8 bhi[NB][2], blo[NB][2];
-            split_acc_tile<NB>(z[t], bhi, blo);
+            split_acc_tile<NB>(zt, bhi, blo);
             mma_chunk_split<NB>(lds + (t & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, y);
             if (t < 3) {
                 wstage_store_linear(ws, lds + ((t + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
@@ -287,6 +316,12 @@ __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeArgs a) {
 // other's matrix work).
 template <int NB, bool FUSE, bool FACT, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void edge_mlp_kernel_occ2(EdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
+    edge_mlp_body<NB, FUSE, FACT, SPLIT>(a, lds);
+}
+
+template <int NB, bool FUSE, bool FACT, bool SPLIT = false>
+__global__ __launch_bounds__(256, 4) void edge_mlp_kernel_occ4(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
     edge_mlp_body<NB, FUSE, FACT, SPLIT>(a, lds);
 }
@@ -781,10 +816,12 @@ extern "C" int msmp_node_project_f32(const float* h, const float* u, const float
     return check_launch("node_proj_kernel");
 }
 
+static int g_edge_occ = 4;     // 4 waves per SIMD (128 registers) measured 5 % faster than 3 (134 registers)
 static int g_edge_nb = 0;    // tuning override (msmp_tune): 0 = automatic, 1 / 2 = force the tile size of the factorised kernel
 
 extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
+    if (key && !strcmp(key, "edge_occ")) { g_edge_occ = value; return MSMP_OK; }
     if (key && !strcmp(key, "lem")) { g_lem_split = value; return MSMP_OK; }
     if (key && !strcmp(key, "split")) { g_split = value; g_lem_split = value; return MSMP_OK; }
     msmp::set_error("msmp_tune: unknown key");
@@ -816,7 +853,8 @@ static int edge_aggregate(const float* h, const float* u, const float* pos, cons
                packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, P, Q, nullptr, agg_out};
     const unsigned grid = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
     timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
-    if (P && edges_per_tile == 128 && g_split) hipLaunchKernelGGL((edge_mlp_kernel_occ2<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (P && edges_per_tile == 128 && g_split && g_edge_occ == 4) hipLaunchKernelGGL((edge_mlp_kernel_occ4<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else if (P && edges_per_tile == 128 && g_split) hipLaunchKernelGGL((edge_mlp_kernel_occ2<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (P && edges_per_tile == 128) hipLaunchKernelGGL((edge_mlp_kernel<1, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (P) hipLaunchKernelGGL((edge_mlp_kernel<2, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((edge_mlp_kernel<2, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

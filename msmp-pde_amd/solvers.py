@@ -29,6 +29,17 @@ def _lin(i, o):
     return nn.Linear(i, o, dtype=torch.float32)
 
 
+def _decoder_autograd(x, conv1, conv2):
+    """output_mlp (Conv1d -> Swish -> Conv1d) for the AUTOGRAD path, written with unfold + einsum so that the backward
+    is plain GEMM / elementwise work: MIOpen's implicit-GEMM backward-data kernel for this shape faulted on MI355X
+    (memory access fault inside igemm_bwd_gtcx35_nhwc_fp32, seen with rocgdb).  x [N, Cin, 128] -> [N, Cout, tw]."""
+    w = x.unfold(2, conv1.kernel_size[0], conv1.stride[0])                          # [N, Cin, L1, k1]
+    mid = torch.einsum('nilk,cik->ncl', w, conv1.weight) + conv1.bias[None, :, None]
+    mid = mid * torch.sigmoid(mid)
+    w2 = mid.unfold(2, conv2.kernel_size[0], 1)                                     # [N, 8, tw, k2]
+    return torch.einsum('nctk,ock->not', w2, conv2.weight) + conv2.bias[None, :, None]
+
+
 class _SolverBase(nn.Module):
     TWO_D = False
     GATED = False
@@ -129,11 +140,13 @@ class _SolverBase(nn.Module):
             gate = self.gnn_layers_gate[i] if self.GATED else None
             h = mp_layer(h, u, pos_x, variables, gs, self.gnn_layers[i], gate)
 
+        grad_path = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.output_mlp.parameters()))
         if self.TWO_D:                  # models_gnn2D.py:125-141
-            diff = self.output_mlp(self.double_mlp(h))
+            hd = self.double_mlp(h)
+            diff = _decoder_autograd(hd, self.output_mlp[0], self.output_mlp[2]) if grad_path else self.output_mlp(hd)
             out = (u.view(-1, 2, tw) + dt.view(1, 1, tw) * diff).flatten(1, 2)
-        elif torch.is_grad_enabled() and any(p.requires_grad for p in self.output_mlp.parameters()):
-            diff = self.output_mlp(h[:, None]).squeeze(1)          # differentiable PyTorch decoder
+        elif grad_path:
+            diff = _decoder_autograd(h[:, None], self.output_mlp[0], self.output_mlp[2]).squeeze(1)   # differentiable decoder
             out = u[:, -1:] + dt.view(1, tw) * diff
         else:                           # models_gnn.py:275-279, fused: conv -> Swish -> conv -> u + cumsum(dt) * diff
             out = torch.empty_like(u)
