@@ -215,6 +215,13 @@ int msmp_decoder_f32(const float* h, const float* u, int64_t n_nodes, int tw, co
                      const float* b1, const float* w2, const float* b2, float dt, float* out,
                      msmp_stream_t stream);
 
+/* *2D solver decoder, experiments/models_gnn2D.py:79-88 (output_mlp for time_window 25 / 50) and :125-141 after
+ * double_mlp:  out = u + cumsum(dt) * Conv1d(8,2,k2)(Swish(Conv1d(2,8,k1,stride)(hd))), hd [N,2,128] = double_mlp(h);
+ * w1 [8,2,k1], b1 [8], w2 [2,8,k2], b2 [2]; u, out [N, 2*tw] (component-major). */
+int msmp_decoder2d_f32(const float* hd, const float* u, int64_t n_nodes, int tw, const float* w1,
+                       const float* b1, const float* w2, const float* b2, float dt, float* out,
+                       msmp_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * In-library kernel timing (measurement aid for bench.py; off by default, not part of the data path)
  * When enabled, every launch of the named kernel family is bracketed by hipEvents recorded on the

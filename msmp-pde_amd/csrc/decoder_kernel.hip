@@ -73,9 +73,119 @@ __global__ __launch_bounds__(256) void decoder_kernel(DecArgs a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Decoder of the *2D solver classes (two solution components), experiments/models_gnn2D.py:79-88, 125-141:
+//   diff = Conv1d(8 -> 2, k2)( Swish( Conv1d(2 -> 8, k1, stride s1)( hd ) ) ),   hd = double_mlp(h)  [N, 2, 128]
+//   out  = unflatten(u) + cumsum(dt) * diff, flattened back to [N, 2*tw]
+// Eight lanes per node, lane c = intermediate channel c: it builds mid[c][:] from both input rows (the eight
+// lanes of a node read the same two 512-B rows: one L1 line fetch serves them), applies Swish, forms its
+// contribution to the 2*tw outputs, and the eight contributions are summed with three xor-shuffles.
+// ----------------------------------------------------------------------------------------------
+struct Dec2Args {
+    const float* hd;     // [N, 2, 128]
+    const float* u;      // [N, 2*tw]
+    long n_nodes;
+    const float* w1;     // [8][2][k1]
+    const float* b1;     // [8]
+    const float* w2;     // [2][8][k2]
+    const float* b2;     // [2]
+    float dt;
+    float* out;          // [N, 2*tw]
+};
+
+template <int TW, int K1, int S1, int K2>
+__global__ __launch_bounds__(256) void decoder2d_kernel(Dec2Args a) {
+    constexpr int L1 = (H - K1) / S1 + 1;
+    static_assert(L1 - K2 + 1 == TW, "decoder geometry");
+    const int c = threadIdx.x & 7;
+    const long n = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
+    float mid[L1];
+    const float bc = a.b1[c];
+#pragma unroll
+    for (int p = 0; p < L1; ++p) mid[p] = bc;
+#pragma unroll 1
+    for (int ci = 0; ci < 2; ++ci) {
+        float x[H];
+        const f32x4* hp = reinterpret_cast<const f32x4*>(a.hd + ((size_t)nc * 2 + ci) * H);
+#pragma unroll
+        for (int i = 0; i < H / 4; ++i) {
+            const f32x4 v = hp[i];
+            x[4 * i] = v[0]; x[4 * i + 1] = v[1]; x[4 * i + 2] = v[2]; x[4 * i + 3] = v[3];
+        }
+        float w[K1];
+#pragma unroll
+        for (int j = 0; j < K1; ++j) w[j] = a.w1[(c * 2 + ci) * K1 + j];
+#pragma unroll
+        for (int p = 0; p < L1; ++p) {
+            float s = mid[p];
+#pragma unroll
+            for (int j = 0; j < K1; ++j) s = fmaf(w[j], x[p * S1 + j], s);
+            mid[p] = s;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < L1; ++p) mid[p] = swishf(mid[p]);
+    float o[2 * TW];
+#pragma unroll
+    for (int co = 0; co < 2; ++co) {
+        float w[K2];
+#pragma unroll
+        for (int j = 0; j < K2; ++j) w[j] = a.w2[(co * 8 + c) * K2 + j];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < K2; ++j) s = fmaf(w[j], mid[t + j], s);
+            o[co * TW + t] = s;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * TW; ++i) {
+        float v = o[i];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        o[i] = v;
+    }
+    if (n >= a.n_nodes) return;
+    const float b20 = a.b2[0], b21 = a.b2[1];
+    float tcum = 0.f;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        tcum += a.dt;
+        // lane c writes the outputs whose flat index i = co*TW + t satisfies i % 8 == c
+#pragma unroll
+        for (int co = 0; co < 2; ++co) {
+            const int i = co * TW + t;
+            if ((i & 7) == c) a.out[(size_t)n * 2 * TW + i] = a.u[(size_t)n * 2 * TW + i] + tcum * (o[i] + (co ? b21 : b20));
+        }
+    }
+}
+
 }  // namespace msmp
 
 using namespace msmp;
+
+extern "C" int msmp_decoder2d_f32(const float* hd, const float* u, int64_t n_nodes, int tw, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, float dt, float* out, msmp_stream_t stream) {
+    MSMP_REQUIRE(hd && u && w1 && b1 && w2 && b2 && out, MSMP_ERR_ARG, "msmp_decoder2d_f32: null pointer");
+    MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31), MSMP_ERR_ARG, "msmp_decoder2d_f32: bad n_nodes");
+    Dec2Args a{hd, u, (long)n_nodes, w1, b1, w2, b2, dt, out};
+    const unsigned grid = (unsigned)((n_nodes + 31) / 32);
+    hipStream_t st = (hipStream_t)stream;
+    timing_begin(MSMP_K_DECODER, st);
+    switch (tw) {   // experiments/models_gnn2D.py:79-88
+        case 25: hipLaunchKernelGGL((decoder2d_kernel<25, 16, 3, 14>), dim3(grid), dim3(256), 0, st, a); break;
+        case 50: hipLaunchKernelGGL((decoder2d_kernel<50, 12, 2, 10>), dim3(grid), dim3(256), 0, st, a); break;
+        default:
+            set_error("msmp_decoder2d_f32: time_window %d (the reference defines 25, 50)", tw);
+            return MSMP_ERR_UNSUPPORTED;
+    }
+    timing_end(MSMP_K_DECODER, st);
+    return check_launch("decoder2d_kernel");
+}
+
 
 extern "C" int msmp_decoder_f32(const float* h, const float* u, int64_t n_nodes, int tw, const float* w1, const float* b1,
                                 const float* w2, const float* b2, float dt, float* out, msmp_stream_t stream) {

@@ -141,10 +141,16 @@ class _SolverBase(nn.Module):
             h = mp_layer(h, u, pos_x, variables, gs, self.gnn_layers[i], gate)
 
         grad_path = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.output_mlp.parameters()))
-        if self.TWO_D:                  # models_gnn2D.py:125-141
-            hd = self.double_mlp(h)
-            diff = _decoder_autograd(hd, self.output_mlp[0], self.output_mlp[2]) if grad_path else self.output_mlp(hd)
+        if self.TWO_D and grad_path:    # models_gnn2D.py:125-141
+            diff = _decoder_autograd(self.double_mlp(h), self.output_mlp[0], self.output_mlp[2])
             out = (u.view(-1, 2, tw) + dt.view(1, 1, tw) * diff).flatten(1, 2)
+        elif self.TWO_D:                # fused: conv(2->8) -> Swish -> conv(8->2) -> u + cumsum(dt) * diff
+            hd = self.double_mlp(h).contiguous()
+            out = torch.empty_like(u)
+            c1, c2 = self.output_mlp[0], self.output_mlp[2]
+            w = [p.detach().to(torch.float32).contiguous() for p in (c1.weight, c1.bias, c2.weight, c2.bias)]   # kept alive
+            check(lib().msmp_decoder2d_f32(ptr(hd), ptr(u), u.shape[0], tw, ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[3]),
+                                           float(self.pde.dt), ptr(out), current_stream()), 'msmp_decoder2d_f32')
         elif grad_path:
             diff = _decoder_autograd(h[:, None], self.output_mlp[0], self.output_mlp[2]).squeeze(1)   # differentiable decoder
             out = u[:, -1:] + dt.view(1, tw) * diff

@@ -407,3 +407,26 @@ def test_decoder_kernel(mp, tw):
     ref = f(u)[:, -1:] + np.cumsum(np.ones(tw) * dt)[None, :] * diff
     err = np.abs(out.double().cpu().numpy() - ref).max()
     assert err < 1e-6, err
+
+
+@pytest.mark.parametrize('tw', [25, 50])
+def test_decoder2d_kernel(mp, tw):
+    """Fused *2D decoder vs the oracle's conv1d restatement."""
+    from msmp_pde_amd._lib import check, ptr, current_stream
+    rng = np.random.default_rng(100 + tw)
+    k1, s1, k2 = O._DECODER[tw]
+    n = 777
+    hd = rng.standard_normal((n, 2, H)).astype(np.float32)
+    u = rng.standard_normal((n, 2 * tw)).astype(np.float32)
+    w1 = (rng.uniform(-1, 1, (8, 2, k1)) / np.sqrt(2 * k1)).astype(np.float32); b1 = rng.uniform(-.2, .2, 8).astype(np.float32)
+    w2 = (rng.uniform(-1, 1, (2, 8, k2)) / np.sqrt(8 * k2)).astype(np.float32); b2 = rng.uniform(-.2, .2, 2).astype(np.float32)
+    dt = 1.0 / 249
+    out = torch.empty(n, 2 * tw, device='cuda')
+    t = [dev(a) for a in (hd, u, w1, b1, w2, b2)]
+    check(mp.lib().msmp_decoder2d_f32(ptr(t[0]), ptr(t[1]), n, tw, ptr(t[2]), ptr(t[3]), ptr(t[4]), ptr(t[5]), dt,
+                                      ptr(out), current_stream()), 'decoder2d')
+    f = lambda a: a.astype(np.float64)
+    diff = O.conv1d(O.swish(O.conv1d(f(hd), f(w1), f(b1), s1)), f(w2), f(b2), 1)
+    ref = (f(u).reshape(n, 2, tw) + np.cumsum(np.ones(tw) * dt)[None, None, :] * diff).reshape(n, 2 * tw)
+    err = np.abs(out.double().cpu().numpy() - ref).max()
+    assert err < 1e-6, err
