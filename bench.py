@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--cpu-sample-graphs', type=int, default=128)
     ap.add_argument('--cpu-sample-steps', type=int, default=3)
     ap.add_argument('--dist-backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo lets two ranks share one GPU for testing')
+    ap.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='msmp_tune override for kernel A/B runs (e.g. lem=1)')
     ap.add_argument('--fp32-mfma', action='store_true', help='use the fp32-MFMA kernels instead of the fp16-split matrix path')
     ap.add_argument('--time-all-kernels', action='store_true', help='event-time every kernel family, not only the dominant one')
     return ap.parse_args()
@@ -108,6 +109,9 @@ def main():
     L = mp.lib()
     split_path = not args.fp32_mfma
     L.msmp_tune(b'split', int(split_path))
+    for kv in args.tune:
+        k, v = kv.split('=')
+        assert L.msmp_tune(k.encode(), int(v)) == 0, kv
 
     exp = args.experiment
     eqv = dict(EXPERIMENTS[exp])

@@ -12,7 +12,8 @@ LIB = os.path.join(PKG, 'libmsmp_pde.so')
 SOURCES = {  # file -> extra flags
     'mlp_kernels.hip': [],
     'aux_kernels.hip': [],
-    'lem_kernel.hip': [],
+    # MFMA results stay in VGPRs (the activations read them with VALU; the stationary weights take the AGPRs)
+    'lem_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
     'decoder_kernel.hip': [],
     'graph_kernels.hip': ['-ffp-contract=off'],   # float64 distance compares must round like the host's
 }

@@ -21,6 +21,13 @@
 namespace msmp {
 
 constexpr int LEM_MAX_INP = 8;
+// input columns as fp16 "slot" fragments (weight-stationary kernel): [4 groups g2,g3,g1,lin][4 T][2 m][64 lanes][8 halfs]
+constexpr int LEM_WXH_FLOATS = 4 * 4 * 2 * 64 * 8 / 2;
+
+// Slot s (0..31) of the K axis of the input MFMAs pairs  A: w_hi[f] | w_hi[f] | w_lo[f]   with   B: x_hi[f] | x_lo[f] | x_hi[f]
+// for s in [0,P) | [P,2P) | [2P,3P)  (zero beyond), so one K=16 MFMA (P <= 5) or two (P <= 8) add W[:, H:] x in fp32-class accuracy.
+__host__ __device__ inline int lem_slot_feature(int slot, int P) { return slot < 3 * P ? slot % P : -1; }
+__host__ __device__ inline int lem_slot_part(int slot, int P) { return slot / P; }   // 0: (hi,hi) 1: (hi,lo) 2: (lo,hi)
 
 // packed LEM blob (floats):  rec (16 chunks: g2 x4, g3 x4, g1 x4, lin x4) | mlp (8 chunks: Wa x4, Wb x4) |
 //   bias [512] (g1, g2, g3, bz in the reference's row order) |
@@ -29,9 +36,10 @@ constexpr int LEM_MAX_INP = 8;
 //   mlp bias [256] (ba, bb)
 //   fp16-split copies for the split kernel (mfma_tiles.h): scales [8] (2^s of W, Wz, Wa, Wb, then 2^-s) |
 //   rec_s (16 split chunks, acc order, same consumption order) | mlp_s (8 split chunks) |
-//   bias_s [512], wxf_s [4096], mlpb_s [256]: the fp32 bias / input-column fragments pre-multiplied by 2^s of their matrix
+//   bias_s [512], wxf_s [4096], mlpb_s [256]: the fp32 bias / input-column fragments pre-multiplied by 2^s of their matrix |
+//   wx_h: the scaled input columns as fp16 slot fragments (see lem_slot_feature)
 struct LemLayout {
-    int64_t rec, mlp, bias, wx, mlpb, scales, rec_s, mlp_s, bias_s, wx_s, mlpb_s, total;
+    int64_t rec, mlp, bias, wx, mlpb, scales, rec_s, mlp_s, bias_s, wx_s, mlpb_s, wx_h, total;
 };
 
 __host__ __device__ inline LemLayout lem_layout() {
@@ -48,6 +56,7 @@ __host__ __device__ inline LemLayout lem_layout() {
     L.bias_s = o; o += 4 * H;
     L.wx_s = o; o += 4 * H * LEM_MAX_INP;
     L.mlpb_s = o; o += 2 * H;
+    L.wx_h = o; o += LEM_WXH_FLOATS;
     L.total = o;
     return L;
 }
@@ -142,6 +151,21 @@ __global__ void pack_lem_split_kernel(LemPackArgs a) {
         a.out[L.wx_s + p] = a.out[L.wx + p] * sc[(p >> 10) < 3 ? 0 : 1];
     for (int64_t p = tid0; p < 2 * H; p += stride)
         a.out[L.mlpb_s + p] = a.out[L.mlpb + p] * sc[p < H ? 2 : 3];
+    _Float16* wh = reinterpret_cast<_Float16*>(a.out + L.wx_h);
+    const int kin = H + a.ninp;
+    for (int64_t p = tid0; p < 2 * LEM_WXH_FLOATS; p += stride) {
+        const int j = (int)(p & 7), lane = (int)(p >> 3) & 63, m = (int)(p >> 9) & 1, T = (int)(p >> 10) & 3, grp = (int)(p >> 12);
+        const int slot = 16 * m + 8 * (lane >> 5) + j, f = lem_slot_feature(slot, a.ninp), row = 32 * T + (lane & 31);
+        _Float16 v = (_Float16)0.f;
+        if (f >= 0) {
+            // groups in consumption order g2, g3, g1 (rows H.., 2H.., 0.. of W), lin (Wz)
+            const float w = (grp == 0 ? a.w[(size_t)(H + row) * kin + H + f] : grp == 1 ? a.w[(size_t)(2 * H + row) * kin + H + f]
+                             : grp == 2 ? a.w[(size_t)row * kin + H + f] : a.wz[(size_t)row * kin + H + f]) * sc[grp < 3 ? 0 : 1];
+            const _Float16 hi = (_Float16)w;
+            v = lem_slot_part(slot, a.ninp) < 2 ? hi : (_Float16)(w - (float)hi);
+        }
+        wh[p] = v;
+    }
 }
 
 __device__ __forceinline__ float tanhf_(float x) {
@@ -656,11 +680,389 @@ __global__ __launch_bounds__(512, 2) void lem_encoder_split2_kernel(LemSplitArgs
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// WEIGHT-STATIONARY edition (default).  The recurrent weights (4 gates x [128 x 128], fp16 hi + lo = 256 KB) fit the
+// CU's register file: a 512-thread workgroup = 4 channel slices x 2 roles, and wave (ks, role) keeps the hi/lo A
+// fragments of TWO gate tiles (rows 32 ks .. 32 ks + 31; 128 registers) for the whole kernel:
+//     role A: g2 (dt_) and g3 (z candidate)  ->  z <- z + dt s(g2) (tanh(g3) - z)      (owns the z slice)
+//     role B: g1 (dt_bar) and lin            ->  y <- y + dt s(g1) (tanh(lin) - y)     (owns the y slice)
+// so each state update is wave-local, no weight ever moves after the prologue, and the only LDS traffic is the
+// hi/lo state fragments every wave publishes for its 32 channels and all waves read as B operands (0.3 KB per MFMA
+// instead of 1 KB with streamed weights, which had the LDS port as busy as the matrix pipe).  A workgroup carries
+// two node tiles (64 nodes) in a two-stage software pipeline, one barrier per stage:
+//     stage 2t + X:     role A works on (tile X, step t):   reads y_X(t),             publishes z_X(t+1)
+//     stage 2t + X + 1: role B works on (tile X, step t):   reads y_X(t), z_X(t+1),   publishes y_X(t+1)
+// (y is double-buffered in LDS because role-B waves still read y_X(t) while others publish y_X(t+1)).  Both waves of a
+// SIMD always have two gate GEMMs (48 + input MFMAs) and 16 registers of activations per stage, and one's VALU
+// overlaps the other's matrix work.  The input columns W[:, H:] x_t are one K=16 fp16 MFMA per gate for ninp <= 5
+// (two for ninp <= 8) through the slot pairing of lem_slot_feature.  s(a) tanh(b) is evaluated with ONE reciprocal:
+//     e_a = 2^(-a log2 e), e_b = 2^(-2 b log2 e), r = 1 / ((1 + e_a)(1 + e_b)):   st += dt r ((1 - e_b) - st (1 + e_b))
+// (exponents clamped at 60 so the product stays finite).
+// ----------------------------------------------------------------------------------------------
+struct LemWsArgs {
+    const float* xin;       // [N, T, 2*NS]
+    long n_nodes;
+    int t_len, with_mlp;
+    float dt;
+    const float* rec_s;     // 16 split chunks (g2, g3, g1, lin)
+    const float* mlp_s;     // 8 split chunks (Wa, Wb)
+    const float* bias_s;    // [512] g1, g2, g3, bz (scaled)
+    const float* wx_h;      // slot fragments
+    const float* mlpb_s;    // [256]
+    const float* scales;    // [8]
+    float* out;
+};
+
+constexpr int LEM_WS_FR = 1024;      // half8 per (tile) fragment area: [kt 4][s 2][plane 2][lane 64]
+
+template <int P>
+__device__ __forceinline__ void lem_ws_load_x(const float* xin, long node, int t, int t_len, float (&x)[2 * ((P + 1) / 2)]) {
+    constexpr int NS = (P + 1) / 2;
+    const f32x2* p = reinterpret_cast<const f32x2*>(xin + ((size_t)node * t_len + t) * (2 * NS));
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const f32x2 v = p[i];
+        x[2 * i] = v[0];
+        x[2 * i + 1] = v[1];
+    }
+}
+
+// B fragments of the input MFMAs from one node's step inputs
+template <int P>
+__device__ __forceinline__ void lem_ws_slots(const float (&x)[2 * ((P + 1) / 2)], int hh, half8 (&bx)[(3 * P + 15) / 16]) {
+    constexpr int M = (3 * P + 15) / 16;
+    _Float16 xh[P], xl[P];
+#pragma unroll
+    for (int f = 0; f < P; ++f) {
+        xh[f] = (_Float16)x[f];
+        xl[f] = (_Float16)(x[f] - (float)xh[f]);
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s0 = 16 * m + j, s1 = 16 * m + 8 + j;
+            const _Float16 v0 = s0 < 3 * P ? (s0 / P == 1 ? xl[s0 % P] : xh[s0 % P]) : (_Float16)0.f;
+            const _Float16 v1 = s1 < 3 * P ? (s1 / P == 1 ? xl[s1 % P] : xh[s1 % P]) : (_Float16)0.f;
+            bx[m][j] = hh ? v1 : v0;
+        }
+}
+
+__device__ __forceinline__ void lem_ws_bias(const float* bl, int hh, f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bl + 8 * q + 4 * hh);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[4 * q + m] = bv[m];
+    }
+}
+
+// publish a [32 channels x 32 nodes] state tile as hi/lo B fragments of K tile `ks`
+__device__ __forceinline__ void lem_ws_publish(const f32x16& st, half8* area, int ks, int lane) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = st[8 * s + j];
+        half8 hi, lo;
+        split8(v, hi, lo);
+        area[((ks * 2 + s) * 2 + 0) * 64 + lane] = hi;
+        area[((ks * 2 + s) * 2 + 1) * 64 + lane] = lo;
+    }
+}
+
+// packed fp32 arithmetic (two values per instruction at the single-value issue cost); the compiler scalarises most
+// <2 x float> expressions, so the activation pipeline names the instructions
+using half2 = __attribute__((ext_vector_type(2))) _Float16;
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {           // a - b
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) {  // c - a b
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// lo = fp16(x - float(hi)) for a pair, one mixed-precision FMA per value
+__device__ __forceinline__ half2 split_lo_pair(half2 hi, f32x2 x) {
+    half2 lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo) : "v"(hi), "v"(x[0]), "v"(x[1]));
+    return lo;
+}
+__device__ __forceinline__ float vmin(float a, float b) {            // bare v_min_f32 (fminf adds a canonicalising v_max)
+    float d;
+    asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+struct LemActConst {
+    f32x2 c0, c1, idt, one;
+};
+
+// st <- st + dt s(a0) (tanh(a1) - st) for one [32 x 32] tile, then publish it as hi/lo B fragments of K tile `ks`.
+// One reciprocal per value: e_a = 2^(c0 a0), e_b = 2^(min(c1 a1, 60)), r = dt / ((1 + e_a)(1 + e_b)),
+// st += r ((1 - e_b) - st (1 + e_b)); e_a = inf gives r = 0 (st unchanged), the clamp keeps (1 - e_b) r finite.
+__device__ __forceinline__ void lem_ws_update_publish(const f32x16& a0, const f32x16& a1, const LemActConst& k, f32x16& st,
+                                                      half8* area, int ks, int lane) {
+    // Staged per half tile, with scheduling barriers between the stages: the compiler's hazard recogniser does not look
+    // inside inline asm, so an accumulator (MFMA result) is first touched by a compiler-emitted multiply, and every
+    // transcendental result is consumed a whole stage later.
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        f32x2 ta[4], tb[4], ea[4], eb[4], qb[4], q[4], rr[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int r = 8 * s + 2 * jj;
+            ta[jj] = f32x2{a0[r] * k.c0[0], a0[r + 1] * k.c0[0]};
+            tb[jj] = f32x2{fminf(a1[r] * k.c1[0], 60.f), fminf(a1[r + 1] * k.c1[0], 60.f)};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            ea[jj] = f32x2{__builtin_amdgcn_exp2f(ta[jj][0]), __builtin_amdgcn_exp2f(ta[jj][1])};
+            eb[jj] = f32x2{__builtin_amdgcn_exp2f(tb[jj][0]), __builtin_amdgcn_exp2f(tb[jj][1])};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            qb[jj] = pk_add(eb[jj], k.one);
+            q[jj] = pk_mul(pk_fma(ea[jj], k.idt, k.idt), qb[jj]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) rr[jj] = f32x2{__builtin_amdgcn_rcpf(q[jj][0]), __builtin_amdgcn_rcpf(q[jj][1])};
+        f32x2 tt[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int r = 8 * s + 2 * jj;
+            tt[jj] = pk_fnma(f32x2{st[r], st[r + 1]}, qb[jj], pk_sub(k.one, eb[jj]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        half8 phi, plo;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int r = 8 * s + 2 * jj;
+            const f32x2 sv = pk_fma(rr[jj], tt[jj], f32x2{st[r], st[r + 1]});
+            st[r] = sv[0];
+            st[r + 1] = sv[1];
+            const half2 hp = __builtin_convertvector(sv, half2);
+            const half2 lp = split_lo_pair(hp, sv);
+            phi[2 * jj] = hp[0];
+            phi[2 * jj + 1] = hp[1];
+            plo[2 * jj] = lp[0];
+            plo[2 * jj + 1] = lp[1];
+        }
+        area[((ks * 2 + s) * 2 + 0) * 64 + lane] = phi;
+        area[((ks * 2 + s) * 2 + 1) * 64 + lane] = plo;
+    }
+}
+
+// acc0 += W0 B0, acc1 += W1 B1 over K = 128 (B0/B1: published fragment areas; they may be the same area)
+template <bool SAME>
+__device__ __forceinline__ void lem_ws_gemm2(const half8 (&w0)[4][2][2], const half8 (&w1)[4][2][2], const half8* b0, const half8* b1,
+                                             int lane, f32x16& acc0, f32x16& acc1) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const half8 h0 = b0[((kt * 2 + s) * 2 + 0) * 64 + lane], l0 = b0[((kt * 2 + s) * 2 + 1) * 64 + lane];
+            half8 h1 = h0, l1 = l0;
+            if (!SAME) {
+                h1 = b1[((kt * 2 + s) * 2 + 0) * 64 + lane];
+                l1 = b1[((kt * 2 + s) * 2 + 1) * 64 + lane];
+            }
+            // three back-to-back MFMAs per accumulator: a dependent MFMA issued right behind its producer accumulates in
+            // place; alternating the two accumulators made every MFMA wait for the previous write-back (2x slower)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][1], h0, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][0], l0, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][0], h0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kt][s][1], h1, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kt][s][0], l1, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kt][s][0], h1, acc1, 0, 0, 0);
+        }
+}
+
+template <int P>
+__global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
+    constexpr int NS = (P + 1) / 2, M = (3 * P + 15) / 16;
+    // y fragments [buffer 2][tile 2] | z fragments [tile 2] (16 KB each) | scaled biases [512 + 256]
+    __shared__ __attribute__((aligned(16))) float lds[6 * SPLIT_CHUNK_FLOATS + 768];
+    half8* const yfr = reinterpret_cast<half8*>(lds);
+    half8* const zfr = yfr + 4 * LEM_WS_FR;
+    float* const bias_l = lds + 6 * SPLIT_CHUNK_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ks = wave & 3, role = wave >> 2;
+    const int c = lane & 31, hh = lane >> 5;
+    const long n0 = (long)blockIdx.x * 64;
+    const float LOG2E = 1.44269504088896340736f;
+    const float inv_w = a.scales[4], inv_z = a.scales[5];
+
+    // prologue: zero y(0) of both tiles (buffer 0), stage the biases, load this wave's stationary weights
+    {
+        half8 zero;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zero[j] = (_Float16)0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yfr[tid + 512 * i] = zero;
+        bias_l[tid] = a.bias_s[tid];
+        if (tid < 256) bias_l[512 + tid] = a.mlpb_s[tid];
+    }
+    half8 w[2][4][2][2];
+    half8 wxh[2][M];
+    {
+        const half8* rs = reinterpret_cast<const half8*>(a.rec_s);
+        const half8* wh = reinterpret_cast<const half8*>(a.wx_h);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int grp = 2 * role + gi;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        w[gi][kt][s][pl] = rs[(size_t)(grp * 4 + kt) * 1024 + ((s * 4 + ks) * 2 + pl) * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < M; ++m) wxh[gi][m] = wh[((grp * 4 + ks) * 2 + m) * 64 + lane];
+        }
+    }
+    // bias rows of the two gates (bias_s order: g1, g2, g3, bz):  role A: g2, g3;  role B: g1, bz
+    const float* bl0 = bias_l + (role ? 0 : H) + 32 * ks;
+    const float* bl1 = bias_l + (role ? 3 * H : 2 * H) + 32 * ks;
+    // exponent constants: gate 0 is the sigmoid gate (W scale); gate 1 the tanh candidate (role A: W, role B: Wz)
+    const float c0 = -inv_w * LOG2E, c1 = -2.0f * (role ? inv_z : inv_w) * LOG2E, idt = 1.0f / a.dt;
+    const LemActConst kc{f32x2{c0, c0}, f32x2{c1, c1}, f32x2{idt, idt}, f32x2{1.0f, 1.0f}};
+
+    f32x16 st[2];
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[X][r] = 0.f;
+
+    long node[2];
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        const long n = n0 + 32 * X + c;
+        node[X] = n < a.n_nodes ? n : a.n_nodes - 1;
+    }
+    float xn[2 * NS];
+    lem_ws_load_x<P>(a.xin, node[0], 0, a.t_len, xn);
+    __syncthreads();
+    if (role) __syncthreads();          // role B runs one stage behind role A
+
+    for (int t = 0; t < a.t_len; ++t) {
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            half8 bx[M];
+            lem_ws_slots<P>(xn, hh, bx);
+            {   // prefetch the inputs of this wave's next work item: (tile 1, t) or (tile 0, t + 1)
+                const int tn = X ? (t + 1 < a.t_len ? t + 1 : t) : t;
+                lem_ws_load_x<P>(a.xin, node[X ^ 1], tn, a.t_len, xn);
+            }
+            f32x16 acc0, acc1;
+            lem_ws_bias(bl0, hh, acc0);
+            lem_ws_bias(bl1, hh, acc1);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxh[0][m], bx[m], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxh[1][m], bx[m], acc1, 0, 0, 0);
+            }
+            const half8* yb = yfr + ((t & 1) * 2 + X) * LEM_WS_FR;
+            if (role) lem_ws_gemm2<false>(w[0], w[1], yb, zfr + X * LEM_WS_FR, lane, acc0, acc1);
+            else lem_ws_gemm2<true>(w[0], w[1], yb, yb, lane, acc0, acc1);
+            lem_ws_update_publish(acc0, acc1, kc, st[X], role ? yfr + (((t + 1) & 1) * 2 + X) * LEM_WS_FR : zfr + X * LEM_WS_FR, ks, lane);
+            __syncthreads();
+        }
+    }
+    if (!role) __syncthreads();         // role A's idle last stage
+    // here: y_X(T) of both tiles is published in buffer T & 1; role-B waves hold their y slices in st[]
+
+    const int X = role;                 // lemoutput_mlp: role A takes tile 0, role B tile 1
+    f32x16 res;
+    if (a.with_mlp) {
+        const half8* ms = reinterpret_cast<const half8*>(a.mlp_s);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        w[gi][kt][s][pl] = ms[(size_t)(gi * 4 + kt) * 1024 + ((s * 4 + ks) * 2 + pl) * 64 + lane];
+        const float invA = a.scales[6], invB = a.scales[7];
+        const half8* yb = yfr + ((a.t_len & 1) * 2 + X) * LEM_WS_FR;
+        half8* hb = zfr + X * LEM_WS_FR;
+        f32x16 acc;
+        lem_ws_bias(bias_l + 512 + 32 * ks, hh, acc);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const half8 h0 = yb[((kt * 2 + s) * 2 + 0) * 64 + lane], l0 = yb[((kt * 2 + s) * 2 + 1) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][kt][s][1], h0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][kt][s][0], l0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][kt][s][0], h0, acc, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = swishf(acc[r] * invA);
+        lem_ws_publish(acc, hb, ks, lane);
+        __syncthreads();
+        lem_ws_bias(bias_l + 512 + H + 32 * ks, hh, res);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const half8 h0 = hb[((kt * 2 + s) * 2 + 0) * 64 + lane], l0 = hb[((kt * 2 + s) * 2 + 1) * 64 + lane];
+                res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][1], h0, res, 0, 0, 0);
+                res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][0], l0, res, 0, 0, 0);
+                res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][0], h0, res, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) res[r] = swishf(res[r] * invB);
+    } else {
+        // y itself: the role-B wave of slice ks holds both tiles; it hands tile 0 to its role-A partner through LDS
+        if (role) *reinterpret_cast<f32x16*>(lds + (size_t)(ks * 64 + lane) * 16) = st[0];
+        __syncthreads();
+        if (role) res = st[1];
+        else res = *reinterpret_cast<const f32x16*>(lds + (size_t)(ks * 64 + lane) * 16);
+    }
+    const long n = n0 + 32 * X + c;
+    if (n < a.n_nodes) {
+        float* o = a.out + (size_t)n * H + 32 * ks + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) v[m] = res[4 * q + m];
+            *reinterpret_cast<f32x4*>(o + 8 * q) = v;
+        }
+    }
+}
+
 }  // namespace msmp
 
 using namespace msmp;
 
-int g_lem_split = 1;     // 1: two-waves-per-SIMD split kernel, 2: one-wave split kernel, 0: fp32 MFMA (msmp_tune "split" / "lem")
+int g_lem_split = 3;     // 3: weight-stationary split kernel, 1: streamed-weight two-waves-per-SIMD split kernel, 2: one-wave split kernel,
+                         // 0: fp32 MFMA (msmp_tune "lem"; "split" 1/0 selects 3/0)
 extern "C" int64_t msmp_packed_lem_floats(void) { return lem_layout().total; }
 
 extern "C" int msmp_pack_lem_f32(const float* weights, const float* weights_lin_z, const float* bias, const float* bias_lin_z,
@@ -689,7 +1091,22 @@ extern "C" int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len
               packed + L.mlpb, h_out};
     const unsigned grid = (unsigned)((n_nodes + 127) / 128);
     timing_begin(MSMP_K_LEM, (hipStream_t)stream);
-    if (g_lem_split == 1) {
+    if (g_lem_split == 3) {
+        LemWsArgs wa{xin, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s, packed + L.mlp_s, packed + L.bias_s,
+                     packed + L.wx_h, packed + L.mlpb_s, packed + L.scales, h_out};
+        const unsigned g64 = (unsigned)((n_nodes + 63) / 64);
+        hipStream_t st = (hipStream_t)stream;
+        switch (ninp) {
+            case 1: hipLaunchKernelGGL(lem_encoder_ws_kernel<1>, dim3(g64), dim3(512), 0, st, wa); break;
+            case 2: hipLaunchKernelGGL(lem_encoder_ws_kernel<2>, dim3(g64), dim3(512), 0, st, wa); break;
+            case 3: hipLaunchKernelGGL(lem_encoder_ws_kernel<3>, dim3(g64), dim3(512), 0, st, wa); break;
+            case 4: hipLaunchKernelGGL(lem_encoder_ws_kernel<4>, dim3(g64), dim3(512), 0, st, wa); break;
+            case 5: hipLaunchKernelGGL(lem_encoder_ws_kernel<5>, dim3(g64), dim3(512), 0, st, wa); break;
+            case 6: hipLaunchKernelGGL(lem_encoder_ws_kernel<6>, dim3(g64), dim3(512), 0, st, wa); break;
+            case 7: hipLaunchKernelGGL(lem_encoder_ws_kernel<7>, dim3(g64), dim3(512), 0, st, wa); break;
+            default: hipLaunchKernelGGL(lem_encoder_ws_kernel<8>, dim3(g64), dim3(512), 0, st, wa); break;
+        }
+    } else if (g_lem_split == 1) {
         LemSplitArgs sa{LemArgs{xin, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s, packed + L.mlp_s, packed + L.bias_s,
                                 packed + L.wx_s, packed + L.mlpb_s, h_out},
                         packed + L.scales};

@@ -14,6 +14,7 @@ constexpr int LDW = 36;                 // LDS row stride (dwords) of a staged c
 constexpr int CHUNK_FLOATS = H * KC;    // one packed chunk: [128 out][32 k]
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // Packed layer blob (floats).  Chunks are [128 out][32 k] row-major, k ascending, zero padded; "split chunks"

@@ -320,7 +320,7 @@ def test_graph_builders_random_grids(mp):
     assert np.array_equal(ei, O.knn_graph(x, 2, np.zeros(10, dtype=np.int64)))
 
 
-@pytest.mark.parametrize('ninp,t_len,n', [(4, 25, 300), (5, 25, 129), (6, 25, 64), (3, 7, 1000), (8, 50, 33)])
+@pytest.mark.parametrize('ninp,t_len,n', [(4, 25, 300), (5, 25, 129), (6, 25, 64), (3, 7, 1000), (8, 50, 33), (1, 5, 70), (2, 3, 64), (7, 4, 200)])
 def test_lem_encoder_kernel(mp, ninp, t_len, n):
     """Fused LEM encoder (recurrence + lemoutput_mlp) vs the float64 oracle cell.  PARITY UNPINNED against
     lem_cuda (absent from the reference); this pins the kernel to the restated cell only."""
@@ -329,8 +329,12 @@ def test_lem_encoder_kernel(mp, ninp, t_len, n):
     mlp = torch.nn.Sequential(torch.nn.Linear(128, 128), mp.Swish(), torch.nn.Linear(128, 128), mp.Swish()).cuda()
     xin = torch.randn(n, t_len, ninp, device='cuda')
     with torch.no_grad():
-        ys = lem.encode(xin, None)           # default: fp16-split matrix path
+        ys = lem.encode(xin, None)           # default: fp16-split matrix path, weight-stationary kernel
         hs = lem.encode(xin, mlp)
+        older = {}
+        for variant in (1, 2):              # streamed-weight split kernels (two waves / one wave per SIMD)
+            mp.lib().msmp_tune(b'lem', variant)
+            older[variant] = (lem.encode(xin, None), lem.encode(xin, mlp))
         mp.lib().msmp_tune(b'split', 0)
         try:
             y = lem.encode(xin, None)        # fp32-MFMA kernel
@@ -350,6 +354,9 @@ def test_lem_encoder_kernel(mp, ninp, t_len, n):
     e_hs = np.abs(hs.double().cpu().numpy() - ref_h).max()
     print(f'lem ninp={ninp} T={t_len}: hip y {e_y:.2e}, hip h {e_h:.2e}, fp16-split y {e_ys:.2e} h {e_hs:.2e}, torch-gpu y {e_t:.2e}')
     assert e_y < 5e-6 and e_h < 5e-6 and e_ys < 5e-6 and e_hs < 5e-6
+    for variant, (yv, hv) in older.items():
+        assert np.abs(yv.double().cpu().numpy() - ref_y).max() < 5e-6, variant
+        assert np.abs(hv.double().cpu().numpy() - ref_h).max() < 5e-6, variant
 
 
 def test_fused_aggregate_degree_limits(mp):
