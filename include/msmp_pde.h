@@ -155,6 +155,18 @@ int msmp_node_update_f32(const float* h, const float* agg, const float* vars, in
 
 /* L4  torch_geometric.nn.InstanceNorm(128) (affine=False, no running stats), experiments/models_gnn.py:
  * 59,66,122,129: per graph g and channel (x-mean)/sqrt(biased var + eps). */
+/* Node tail of one layer in one launch: update head(s) + InstanceNorm (+ gated blend), for batches whose graphs have at
+ * most 128 nodes (MSMP_ERR_UNSUPPORTED otherwise, and on the fp32-MFMA path: chain the piecewise entry points there).
+ *   packed_gate == NULL: out = InstanceNorm(update(h, agg_main))                 GNN_Layer / GNN_LayerLin.forward tail,
+ *                                                                                experiments/models_gnn.py:61-67,80-86 / 124-130,143-149
+ *   packed_gate != NULL: out = (1 - tau) h + tau Swish(IN(update_main)),  tau = sigmoid(IN(update_gate))       :1366-1368
+ * agg_* [N,128] are the mean-aggregated messages of the respective head (msmp_edge_aggregate*_f32); graph_ptr
+ * [n_graphs+1]; mode as in msmp_node_update_f32.  The pre-norm tensors stay in registers. */
+int msmp_node_tail_f32(const float* h, const float* agg_main, const float* agg_gate, const float* vars,
+                       const int32_t* graph_ptr, int64_t n_nodes, int64_t n_graphs, int max_graph_nodes, int nv,
+                       const float* packed_main, const float* packed_gate, int mode, float eps, float* out,
+                       msmp_stream_t stream);
+
 /* max_graph_nodes = size of the largest graph (0 if unknown): up to 128 nodes the rows of a graph are read once
  * and kept in registers across the three passes; larger graphs use the generic kernels (same results). */
 int msmp_instance_norm_f32(const float* x, const int32_t* graph_ptr, int64_t n_graphs,

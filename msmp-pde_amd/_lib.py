@@ -42,6 +42,7 @@ SIGNATURES = {
     'msmp_lem_encoder_f32': (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     'msmp_decoder_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     'msmp_decoder2d_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    'msmp_node_tail_f32': (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     'msmp_timing_enable': (c_int, [c_int]),
     'msmp_timing_reset': (c_int, []),
     'msmp_timing_read': (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),

@@ -153,6 +153,28 @@ __global__ void pack_layer_split_kernel(PackArgs a) {
         if (ch < 12) out_a[p] = val;
         else out_b[p - 12 * 8192] = val;
     }
+    // update_net_2 once more with the rows dealt round-robin over the four tiles (row of (T, lane) = 4 (lane & 31) + T)
+    _Float16* out_t = reinterpret_cast<_Float16*>(a.out + L.w4t);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < (int64_t)4 * 8192; p += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(p >> 13), idx = (int)(p & 8191);
+        const int j = idx & 7, lane = (idx >> 3) & 63, plane = (idx >> 9) & 1, T = (idx >> 10) & 3, s = (idx >> 12) & 1;
+        const float w = a.w4[(size_t)(4 * (lane & 31) + T) * H + 32 * ch + split_k_acc(s, lane >> 5, j)] * sc[3];
+        const _Float16 hi = (_Float16)w;
+        out_t[p] = plane == 0 ? hi : (_Float16)(w - (float)hi);
+    }
+    // variables columns of update_net_1 as slot fragments (A operand: lane = row, slots 16 m + 8 h + j)
+    _Float16* out_v = reinterpret_cast<_Float16*>(a.out + L.w3vh);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < 2 * VAR_SLOT_FLOATS; p += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(p & 7), lane = (int)(p >> 3) & 63, T = (int)(p >> 9) & 3, m = (int)(p >> 11);
+        const int slot = 16 * m + 8 * (lane >> 5) + j, f = slot & 7, part = var_slot_part(slot), row = 32 * T + (lane & 31);
+        _Float16 v = (_Float16)0.f;
+        if (part < 3 && f < a.nv) {
+            const float w = a.w3[(size_t)row * k3 + 2 * H + f] * sc[2];
+            const _Float16 hi = (_Float16)w;
+            v = part < 2 ? hi : (_Float16)(w - (float)hi);
+        }
+        out_v[p] = v;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -464,14 +486,14 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
     float* msg = (float*)ws;
     if (!fused) ws += align256((size_t)n_edges * H * sizeof(float));
     const size_t nod = align256((size_t)n_nodes * H * sizeof(float));
-    float* agg = (float*)ws;
+    float* const agg = (float*)ws;
     float* pre_main = (float*)(ws + nod);
     float* pre_gate = (float*)(ws + 2 * nod);
     float* pbuf = (float*)(ws + 3 * nod);
     float* qbuf = (float*)(ws + 4 * nod);
     int rc;
     // message + mean (rows L1 + L2): one fused launch when every target's in-edges fit a workgroup tile
-    auto aggregate = [&](const float* packed) -> int {
+    auto aggregate = [&](const float* packed, float* agg) -> int {
         if (fused && !dense) {
             const int r = msmp_node_project_f32(h, u, pos, vars, n_nodes, tw, nv, packed, pbuf, qbuf, stream);
             return r ? r : msmp_edge_aggregate_projected_f32(pbuf, qbuf, rowptr, col, tgt, n_nodes, n_edges, max_in_degree, tw,
@@ -483,11 +505,18 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
         const int r = msmp_edge_mlp_f32(h, u, pos, vars, tgt, col, n_nodes, n_edges, tw, nv, packed, msg, stream);
         return r ? r : msmp_scatter_mean_f32(msg, rowptr, n_nodes, agg, stream);
     };
+    // node tail (rows L3-L5): one launch per layer when the graphs fit a workgroup (update head(s) + InstanceNorm + blend)
+    if (msmp_tune_get("split") && msmp_tune_get("tail") && max_graph_nodes > 0 && max_graph_nodes <= 128) {
+        if (gated && (rc = aggregate(packed_gate, pre_gate))) return rc;       // pre_gate doubles as the gate head's aggregate
+        if ((rc = aggregate(packed_main, agg))) return rc;
+        return msmp_node_tail_f32(h, agg, gated ? pre_gate : nullptr, vars, graph_ptr, n_nodes, n_graphs, max_graph_nodes, nv,
+                                  packed_main, packed_gate, mode, eps, h_out, stream);
+    }
     if (gated) {
-        if ((rc = aggregate(packed_gate))) return rc;
+        if ((rc = aggregate(packed_gate, agg))) return rc;
         if ((rc = msmp_node_update_f32(h, agg, vars, n_nodes, nv, packed_gate, MSMP_LAYER_LIN, pre_gate, stream))) return rc;
     }
-    if ((rc = aggregate(packed_main))) return rc;
+    if ((rc = aggregate(packed_main, agg))) return rc;
     if ((rc = msmp_node_update_f32(h, agg, vars, n_nodes, nv, packed_main, mode, pre_main, stream))) return rc;
     if (gated) return msmp_gate_blend_f32(h, pre_gate, pre_main, graph_ptr, n_graphs, max_graph_nodes, eps, h_out, stream);
     return msmp_instance_norm_f32(pre_main, graph_ptr, n_graphs, max_graph_nodes, eps, h_out, stream);

@@ -109,6 +109,19 @@ __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo
     }
 }
 
+// Per-node scalar columns (the <= 8 equation variables) enter a split GEMM as two K=16 fp16 MFMAs.  K slot s pairs
+//   s in [0,8): w_hi[f] x_hi[f]     [8,16): w_hi[f] x_lo[f]     [16,24): w_lo[f] x_hi[f]     [24,32): zero      (f = s & 7)
+// so the node side needs no indexing: k-step 0 is (x_hi | x_lo) on the (hh = 0 | 1) lanes, k-step 1 is (x_hi | 0).
+__host__ __device__ inline int var_slot_part(int slot) { return slot >> 3; }      // 0: hi*hi  1: hi*lo  2: lo*hi  3: unused
+__device__ __forceinline__ void var_slot_frags(const float (&x)[8], int hh, half8 (&bx)[2]) {
+    half8 xh, xl, zero;
+    split8(x, xh, xl);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (_Float16)0.f;
+    bx[0] = hh ? xl : xh;
+    bx[1] = hh ? zero : xh;
+}
+
 __device__ __forceinline__ void wstage_store_linear(const WStage& s, float* buf, int tid) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(buf + 4 * (tid + 256 * i)) = s.r[i];

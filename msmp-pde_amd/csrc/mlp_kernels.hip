@@ -694,40 +694,57 @@ struct NodeSplitArgs {
     const float* scales;  // [8]
 };
 
-__global__ __launch_bounds__(256, 2) void node_update_split_kernel(NodeSplitArgs sa) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS];
-    const NodeArgs& a = sa.b;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 31, hh = lane >> 5;
-    const long n = (long)blockIdx.x * 128 + wave * 32 + c;
-    const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
-    const float sc3 = sa.scales[2], inv3 = sa.scales[6], sc4 = sa.scales[3], inv4 = sa.scales[7];
-
+// One update head on the split path: y = (W4 Swish(W3 [h ; agg ; vars] + b3) + b4) in accumulator layout (one node per lane),
+// already multiplied by 2^-s4.  Ends with the weight buffers free (no barrier pending).
+__device__ __forceinline__ void node_head_split(const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ vars,
+                                                long nc, int nv, const float* b3, const float* b4, const float* w3v, const float* w3s,
+                                                const float* scales, float* lds, int tid, int lane, int hh, f32x16 (&y)[4][1]) {
+    const float sc3 = scales[2], inv3 = scales[6], sc4 = scales[3], inv4 = scales[7];
     // acc init = (b3 + W3[:, 256:256+nv] vars_n) * 2^s3
     f32x16 z[4][1];
-    acc_init_bias<1>(a.b3, hh, z);
-    for (int v = 0; v < a.nv; ++v) {
-        const float xv = a.vars[(size_t)nc * a.nv + v];
+    acc_init_bias<1>(b3, hh, z);
+    for (int v = 0; v < nv; ++v) {
+        const float xv = vars[(size_t)nc * nv + v];
 #pragma unroll
         for (int T = 0; T < 4; ++T)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                z[T][0][r] = fmaf(a.w3v[(32 * T + acc_row(r, hh)) * MSMP_MAX_VARS + v], xv, z[T][0][r]);
+                z[T][0][r] = fmaf(w3v[(32 * T + acc_row(r, hh)) * MSMP_MAX_VARS + v], xv, z[T][0][r]);
     }
 #pragma unroll
     for (int T = 0; T < 4; ++T)
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[T][0][r] *= sc3;
 
+    // The lane's slices of its h / agg rows (B operand of the 8 k-chunks) are prefetched FOUR chunks ahead: the loop is
+    // a chain of short MFMA bursts between barriers, and a row load issued right before its use exposed the HBM
+    // latency once per chunk (the kernel ran at a third of its matrix-pipe time).
+    f32x4 pf[4][4];
+    auto row_load = [&](int ch, f32x4 (&dst)[4]) {
+        const float* row32 = (ch < 4 ? h : agg) + (size_t)nc * H + 32 * (ch & 3);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            dst[2 * s] = *reinterpret_cast<const f32x4*>(row32 + 16 * s + 8 * hh);
+            dst[2 * s + 1] = *reinterpret_cast<const f32x4*>(row32 + 16 * s + 8 * hh + 4);
+        }
+    };
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) row_load(ch, pf[ch]);
     WStage ws;
-    wstage_load(ws, sa.w3s, tid);
+    wstage_load(ws, w3s, tid);
     wstage_store_linear(ws, lds, tid);
     __syncthreads();
-#pragma unroll 1
+#pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
-        wstage_load(ws, sa.w3s + (size_t)(ch + 1) * SPLIT_CHUNK_FLOATS, tid);      // chunk 8 = w4s chunk 0
+        wstage_load(ws, w3s + (size_t)(ch + 1) * SPLIT_CHUNK_FLOATS, tid);      // chunk 8 = w4s chunk 0
         half8 bhi[1][2], blo[1][2];
-        gather_split_row((ch < 4 ? a.h : a.agg) + (size_t)nc * H + 32 * (ch & 3), hh, bhi, blo);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 v0 = pf[ch & 3][2 * s], v1 = pf[ch & 3][2 * s + 1];
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            split8(v, bhi[0][s], blo[0][s]);
+        }
+        if (ch + 4 < 8) row_load(ch + 4, pf[ch & 3]);
         mma_chunk_split<1>(lds + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, z);
         wstage_store_linear(ws, lds + ((ch + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
         __syncthreads();
@@ -737,9 +754,8 @@ __global__ __launch_bounds__(256, 2) void node_update_split_kernel(NodeSplitArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[T][0][r] = swishf(z[T][0][r] * inv3);
 
-    f32x16 y[4][1];
-    acc_init_bias_scaled<1>(a.b4, sc4, hh, y);
-    const float* w4s = sa.w3s + 8 * SPLIT_CHUNK_FLOATS;
+    acc_init_bias_scaled<1>(b4, sc4, hh, y);
+    const float* w4s = w3s + 8 * SPLIT_CHUNK_FLOATS;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         if (t < 3) wstage_load(ws, w4s + (size_t)(t + 1) * SPLIT_CHUNK_FLOATS, tid);
@@ -751,6 +767,21 @@ __global__ __launch_bounds__(256, 2) void node_update_split_kernel(NodeSplitArgs
             __syncthreads();
         }
     }
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[T][0][r] *= inv4;
+}
+
+__global__ __launch_bounds__(256, 2) void node_update_split_kernel(NodeSplitArgs sa) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS];
+    const NodeArgs& a = sa.b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const long n = (long)blockIdx.x * 128 + wave * 32 + c;
+    const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
+    f32x16 y[4][1];
+    node_head_split(a.h, a.agg, a.vars, nc, a.nv, a.b3, a.b4, a.w3v, sa.w3s, sa.scales, lds, tid, lane, hh, y);
     if (n < a.n_nodes) {
         float* o = a.out + (size_t)n * H + 4 * hh;
         const float* hx = a.h + (size_t)n * H + 4 * hh;
@@ -761,15 +792,318 @@ __global__ __launch_bounds__(256, 2) void node_update_split_kernel(NodeSplitArgs
                 f32x4 v;
                 if (a.mode == MSMP_LAYER_LIN) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) v[m] = y[T][0][4 * q + m] * inv4;
+                    for (int m = 0; m < 4; ++m) v[m] = y[T][0][4 * q + m];
                 } else {
                     const f32x4 x = *reinterpret_cast<const f32x4*>(hx + 32 * T + 8 * q);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) v[m] = x[m] + swishf(y[T][0][4 * q + m] * inv4);
+                    for (int m = 0; m < 4; ++m) v[m] = x[m] + swishf(y[T][0][4 * q + m]);
                 }
                 *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = v;
             }
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Node tail of one layer in ONE launch (graphs of at most 128 nodes, one graph per workgroup):
+//   gated pair (experiments/models_gnn.py:1366-1368):  h' = (1 - tau) h + tau Swish(IN(update_main)),  tau = sigmoid(IN(update_gate))
+//   plain layer (:61-67 / :124-130):                    h' = IN(update)   (update = h + Swish(..) or the Lin form)
+// IN = PyG InstanceNorm over the graph's nodes (biased variance, eps).  The pre-norm tensors never leave registers.
+// update_net_1 is computed channel-major as in the other kernels (a node per lane); update_net_2 is computed TRANSPOSED
+// (the Swish output fragments become the A operand, the W4 fragments the B operand), so its accumulator holds
+// [32 nodes of the wave][channel = lane]: the per-channel sums over the graph are 16 in-lane adds per tile plus eight
+// partials through LDS, each lane needs the statistics of four channels only, and h / h' move as 128-B rows.
+// The variables columns are two fp16 slot MFMAs (var_slot_frags).  Against node_update x2 + gate_blend this reads
+// h, agg_main, agg_gate and writes h' (420 MB instead of 1050 MB at 2048 x 100 nodes).
+// ----------------------------------------------------------------------------------------------
+// Phase profile of the tail kernel (build with MSMP_PROF=1 in the environment of build.py; scripts/prof_tail.py reads it):
+// per-workgroup cycle sums of wave 0, kept in scalar registers and added to g_prof once at the end.
+#if MSMP_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_DECL long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tp = __builtin_readcyclecounter();
+#define PROF_ARGS , long long& tp, long long (&pacc)[12]
+#define PROF_PASS , tp, pacc
+#define PROF_MARK(i) do { const long long t_ = __builtin_readcyclecounter(); pacc[i] += t_ - tp; tp = t_; } while (0)
+#define PROF_FLUSH if (tid == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_prof[i_], (unsigned long long)pacc[i_]);
+#else
+#define PROF_DECL
+#define PROF_ARGS
+#define PROF_PASS
+#define PROF_MARK(i)
+#define PROF_FLUSH
+#endif
+
+struct TailArgs {
+    const float* h;
+    const float* agg[2];     // main, gate
+    const float* vars;
+    const int* graph_ptr;
+    int nv, mode;
+    float eps;
+    const float* b3[2];
+    const float* b4[2];
+    const float* w3vh[2];
+    const float* w3s[2];
+    const float* w4t[2];
+    const float* scales[2];
+    float* out;
+};
+
+// One update head, update_net_2 transposed: yT[T][r] = 2^s4 (W4 Swish(W3 [h ; agg ; vars] + b3) + b4)[channel 4 c + T]
+// of node acc_row(r, hh) of the wave's 32-node tile (the w4t fragments deal the output channels round-robin over the
+// four tiles, so a lane owns four CONSECUTIVE channels and h / h' move as 16-byte pieces of 512-byte rows).
+// head_rows_issue starts the loads of the lane's slices of its h / agg rows for k-chunks 0..3 (the gated kernel issues
+// the main head's during the gate head's update_net_2); head_compute ends with the weight buffers free.
+struct HeadRows {
+    f32x4 pf[4][4];
+};
+__device__ __forceinline__ void head_row_load(const float* __restrict__ h, const float* __restrict__ agg, long nc, int hh, int ch,
+                                              f32x4 (&dst)[4]) {
+    const float* row32 = (ch < 4 ? h : agg) + (size_t)nc * H + 32 * (ch & 3);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        dst[2 * s] = *reinterpret_cast<const f32x4*>(row32 + 16 * s + 8 * hh);
+        dst[2 * s + 1] = *reinterpret_cast<const f32x4*>(row32 + 16 * s + 8 * hh + 4);
+    }
+}
+__device__ __forceinline__ void head_rows_issue(const float* __restrict__ h, const float* __restrict__ agg, long nc, int hh, HeadRows& st) {
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) head_row_load(h, agg, nc, hh, ch, st.pf[ch]);
+}
+
+template <typename MidHook>
+__device__ __forceinline__ void head_compute(HeadRows& st, const float* __restrict__ h, const float* __restrict__ agg,
+                                             const float* __restrict__ vars, long nc, int nv, const float* b3, const float* b4,
+                                             const float* w3vh, const float* w3s, const float* w4t, const float* scales, float* lds,
+                                             int tid, int lane, int c, int hh, f32x16 (&yT)[4], MidHook mid_hook PROF_ARGS) {
+    const float sc3 = scales[2], inv3 = scales[6], sc4 = scales[3];
+    WStage ws;
+    wstage_load(ws, w3s, tid);
+    float xv[8];
+    half8 wvf[2][4];
+    f32x16 z[4][1];
+    acc_init_bias_scaled<1>(b3, sc3, hh, z);
+    wstage_store_linear(ws, lds, tid);
+    __syncthreads();
+    PROF_MARK(5);
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        wstage_load(ws, ch < 7 ? w3s + (size_t)(ch + 1) * SPLIT_CHUNK_FLOATS : w4t, tid);
+        half8 bhi[1][2], blo[1][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 v0 = st.pf[ch & 3][2 * s], v1 = st.pf[ch & 3][2 * s + 1];
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            split8(v, bhi[0][s], blo[0][s]);
+        }
+        if (ch + 4 < 8) head_row_load(h, agg, nc, hh, ch + 4, st.pf[ch & 3]);
+        if (ch == 5) {      // the variables and their slot fragments are consumed after the k loop: issued two chunks ahead
+#pragma unroll
+            for (int f = 0; f < 8; ++f) xv[f] = f < nv ? vars[(size_t)nc * nv + f] : 0.f;
+            const half8* wv = reinterpret_cast<const half8*>(w3vh) + lane;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int T = 0; T < 4; ++T) wvf[m][T] = wv[(m * 4 + T) * 64];
+        }
+        PROF_MARK(6);
+        mma_chunk_split<1>(lds + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, z);
+        PROF_MARK(7);
+        wstage_store_linear(ws, lds + ((ch + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+        PROF_MARK(8);
+        __syncthreads();
+        PROF_MARK(9);
+    }
+    {
+        half8 bx[2];
+        var_slot_frags(xv, hh, bx);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int T = 0; T < 4; ++T) z[T][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wvf[m][T], bx[m], z[T][0], 0, 0, 0);
+    }
+    mid_hook();             // the row registers are free from here on
+    PROF_MARK(10);
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[T][0][r] = swishf(z[T][0][r] * inv3);
+
+    {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b4 + 4 * c) * sc4;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yT[T][r] = bv[T];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t < 3) wstage_load(ws, w4t + (size_t)(t + 1) * SPLIT_CHUNK_FLOATS, tid);
+        half8 zhi[1][2], zlo[1][2];
+        split_acc_tile<1>(z[t], zhi, zlo);
+        const half8* w = reinterpret_cast<const half8*>(lds + (t & 1) * SPLIT_CHUNK_FLOATS) + lane;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                const half8 whi = w[((s * 4 + T) * 2 + 0) * 64], wlo = w[((s * 4 + T) * 2 + 1) * 64];
+                yT[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zhi[0][s], wlo, yT[T], 0, 0, 0);
+                yT[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zlo[0][s], whi, yT[T], 0, 0, 0);
+                yT[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zhi[0][s], whi, yT[T], 0, 0, 0);
+            }
+        if (t < 3) {
+            wstage_store_linear(ws, lds + ((t + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+            __syncthreads();
+        }
+    }
+}
+
+// per-channel total over the workgroup of one per-lane value per channel tile (lane = channel 32 T + c; the two hh halves
+// and the four waves hold partial sums): returns the totals of this lane's four channels
+__device__ __forceinline__ void tile_t_total(const float (&v)[4], float* part, float* tot, int tid, int wave, int c, int hh,
+                                             float (&out)[4]) {
+#pragma unroll
+    for (int T = 0; T < 4; ++T) part[(wave * 2 + hh) * H + 32 * T + c] = v[T];
+    __syncthreads();
+    if (tid < H) {
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) s += part[p * H + tid];
+        tot[tid] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int T = 0; T < 4; ++T) out[T] = tot[32 * T + c];
+}
+
+// x <- (x - mean) / sqrt(var + eps) per channel over the graph's cnt nodes; x is in units of `unit` (a power of two)
+__device__ __forceinline__ void tile_t_instance_norm(f32x16 (&x)[4], int wave, int cnt, float unit, float eps, float* part, float* tot,
+                                                     int tid, int c, int hh) {
+    const float inv = 1.0f / (float)max(cnt, 1);
+    const bool ragged = wave * 32 + 32 > cnt;       // wave-uniform: some of this wave's 32 nodes lie past the graph
+    if (ragged) {
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[T][r] = wave * 32 + acc_row(r, hh) < cnt ? x[T][r] : 0.f;
+    }
+    float s[4], m[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) { a0 += x[T][r]; a1 += x[T][r + 1]; }
+        s[T] = a0 + a1;
+    }
+    tile_t_total(s, part, tot, tid, wave, c, hh, m);
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        const float mean = m[T] * inv;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            x[T][r] -= mean;
+            x[T][r + 1] -= mean;
+            if (ragged) {
+                x[T][r] = wave * 32 + acc_row(r, hh) < cnt ? x[T][r] : 0.f;
+                x[T][r + 1] = wave * 32 + acc_row(r + 1, hh) < cnt ? x[T][r + 1] : 0.f;
+            }
+            a0 = fmaf(x[T][r], x[T][r], a0);
+            a1 = fmaf(x[T][r + 1], x[T][r + 1], a1);
+        }
+        s[T] = a0 + a1;
+    }
+    tile_t_total(s, part, tot, tid, wave, c, hh, m);
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        const float f = unit * __builtin_amdgcn_rsqf(m[T] * inv * unit * unit + eps);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[T][r] *= f;
+    }
+}
+
+template <bool GATED>
+__global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS];
+    __shared__ float part[8 * H];
+    __shared__ float tot[H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const int n0 = a.graph_ptr[blockIdx.x], n1 = a.graph_ptr[blockIdx.x + 1];
+    const int cnt = n1 - n0;
+    if (cnt <= 0) return;
+    const long n = (long)n0 + wave * 32 + c;
+    const long nc = n < n1 ? n : n1 - 1;
+
+    PROF_DECL
+    HeadRows rows;
+    f32x16 tau[4];
+    if (GATED) {
+        head_rows_issue(a.h, a.agg[1], nc, hh, rows);
+        head_compute(rows, a.h, a.agg[1], a.vars, nc, a.nv, a.b3[1], a.b4[1], a.w3vh[1], a.w3s[1], a.w4t[1], a.scales[1], lds, tid, lane,
+                     c, hh, tau, [&] { head_rows_issue(a.h, a.agg[0], nc, hh, rows); } PROF_PASS);
+        PROF_MARK(0);
+        tile_t_instance_norm(tau, wave, cnt, a.scales[1][7], a.eps, part, tot, tid, c, hh);
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tau[T][r] = sigmoidf_(tau[T][r]);
+        PROF_MARK(1);
+    } else {
+        head_rows_issue(a.h, a.agg[0], nc, hh, rows);
+    }
+    f32x16 y[4];
+    head_compute(rows, a.h, a.agg[0], a.vars, nc, a.nv, a.b3[0], a.b4[0], a.w3vh[0], a.w3s[0], a.w4t[0], a.scales[0], lds, tid, lane, c, hh,
+                 y, [] {} PROF_PASS);
+    PROF_MARK(2);
+    // this lane's piece of the transposed tiles: nodes n0 + 32 wave + acc_row(r, hh), channels 4 c .. 4 c + 3 (tile T = channel 4 c + T)
+    const size_t base = ((size_t)n0 + wave * 32 + 4 * hh) * H + 4 * c;
+    const int lim = cnt - wave * 32 - 4 * hh;          // register r is a node of the graph iff (r & 3) + 8 (r >> 2) < lim
+    const bool full = wave * 32 + 32 <= cnt;           // wave-uniform: all 32 nodes of this wave belong to the graph
+    const bool need_h = GATED || a.mode != MSMP_LAYER_LIN;
+    // h for the residual / blend: all 16 loads are issued here, ahead of the norm's barriers, and unpredicated on the common path
+    // (loads and stores predicated per row became separately waited-for blocks: 40 % of the kernel)
+    f32x4 hx[16];
+    if (need_h) {
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hx[r] = *reinterpret_cast<const f32x4*>(a.h + base + (size_t)((r & 3) + 8 * (r >> 2)) * H);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2);
+                hx[r] = row < lim ? *reinterpret_cast<const f32x4*>(a.h + base + (size_t)row * H) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+    float unit = a.scales[0][7];
+    if (!GATED && a.mode != MSMP_LAYER_LIN) {
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[T][r] = hx[r][T] + swishf(y[T][r] * unit);
+        unit = 1.0f;
+    }
+    tile_t_instance_norm(y, wave, cnt, unit, a.eps, part, tot, tid, c, hh);
+    PROF_MARK(3);
+    if (GATED) {
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[T][r] = fmaf(tau[T][r], swishf(y[T][r]) - hx[r][T], hx[r][T]);
+    }
+    if (full) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            *reinterpret_cast<f32x4*>(a.out + base + (size_t)((r & 3) + 8 * (r >> 2)) * H) = f32x4{y[0][r], y[1][r], y[2][r], y[3][r]};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2);
+            if (row < lim) *reinterpret_cast<f32x4*>(a.out + base + (size_t)row * H) = f32x4{y[0][r], y[1][r], y[2][r], y[3][r]};
+        }
+    }
+    PROF_MARK(4);
+    PROF_FLUSH
 }
 
 }  // namespace msmp
@@ -819,7 +1153,15 @@ extern "C" int msmp_node_project_f32(const float* h, const float* u, const float
 static int g_edge_occ = 4;     // 4 waves per SIMD (128 registers) measured 5 % faster than 3 (134 registers)
 static int g_edge_nb = 0;    // tuning override (msmp_tune): 0 = automatic, 1 / 2 = force the tile size of the factorised kernel
 
+static int g_tail = 1;       // fused node tail (msmp_node_tail_f32) inside msmp_mp_layer_f32; msmp_tune("tail", 0) chains the pieces
+int msmp_tune_get(const char* key) {
+    if (!strcmp(key, "split")) return g_split;
+    if (!strcmp(key, "tail")) return g_tail;
+    return 0;
+}
+
 extern "C" int msmp_tune(const char* key, int value) {
+    if (key && !strcmp(key, "tail")) { g_tail = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_occ")) { g_edge_occ = value; return MSMP_OK; }
     if (key && !strcmp(key, "lem")) { g_lem_split = value; return MSMP_OK; }
@@ -877,6 +1219,39 @@ extern "C" int msmp_edge_aggregate_projected_f32(const float* p, const float* q,
     MSMP_REQUIRE(p && q, MSMP_ERR_ARG, "msmp_edge_aggregate_projected_f32: null pointer");
     return edge_aggregate(nullptr, nullptr, nullptr, nullptr, p, q, rowptr, col, tgt, n_nodes, n_edges, max_in_degree, tw, nv,
                           packed, agg_out, stream, "msmp_edge_aggregate_projected_f32");
+}
+
+#if MSMP_PROF
+extern "C" __attribute__((visibility("default"))) int msmp_debug_prof(unsigned long long* out16, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long));
+}
+#endif
+
+extern "C" int msmp_node_tail_f32(const float* h, const float* agg_main, const float* agg_gate, const float* vars,
+                                  const int32_t* graph_ptr, int64_t n_nodes, int64_t n_graphs, int max_graph_nodes, int nv,
+                                  const float* packed_main, const float* packed_gate, int mode, float eps, float* out,
+                                  msmp_stream_t stream) {
+    MSMP_REQUIRE(h && agg_main && vars && graph_ptr && packed_main && out, MSMP_ERR_ARG, "msmp_node_tail_f32: null pointer");
+    MSMP_REQUIRE((agg_gate != nullptr) == (packed_gate != nullptr), MSMP_ERR_ARG, "msmp_node_tail_f32: give both gate arguments or none");
+    MSMP_REQUIRE(n_nodes > 0 && n_graphs > 0 && n_graphs < (1L << 31) && nv >= 1 && nv <= MSMP_MAX_VARS, MSMP_ERR_ARG,
+                 "msmp_node_tail_f32: bad sizes");
+    MSMP_REQUIRE(mode == MSMP_LAYER_LIN || mode == MSMP_LAYER_RESIDUAL_SWISH, MSMP_ERR_ARG, "msmp_node_tail_f32: bad mode %d", mode);
+    MSMP_REQUIRE(!packed_gate || mode == MSMP_LAYER_LIN, MSMP_ERR_ARG, "msmp_node_tail_f32: the gated pair uses GNN_LayerLin layers");
+    MSMP_REQUIRE(out != h, MSMP_ERR_ARG, "msmp_node_tail_f32: out may not alias h");
+    MSMP_REQUIRE(max_graph_nodes > 0 && max_graph_nodes <= 128, MSMP_ERR_UNSUPPORTED,
+                 "msmp_node_tail_f32: graphs of up to 128 nodes (got max_graph_nodes=%d); use the piecewise entry points", max_graph_nodes);
+    MSMP_REQUIRE(g_split, MSMP_ERR_UNSUPPORTED, "msmp_node_tail_f32: only on the fp16-split matrix path");
+    const PackedLayout L = packed_layout(1, nv);   // w3/w4/b3/b4/w3v/w3s/scales offsets do not depend on tw
+    const float* pg = packed_gate ? packed_gate : packed_main;
+    TailArgs a{h, {agg_main, agg_gate}, vars, graph_ptr, nv, mode, eps,
+               {packed_main + L.b3, pg + L.b3}, {packed_main + L.b4, pg + L.b4}, {packed_main + L.w3vh, pg + L.w3vh},
+               {packed_main + L.w3s, pg + L.w3s}, {packed_main + L.w4t, pg + L.w4t}, {packed_main + L.scales, pg + L.scales}, out};
+    timing_begin(MSMP_K_NODE_UPDATE, (hipStream_t)stream);
+    if (packed_gate) hipLaunchKernelGGL(node_tail_split_kernel<true>, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(node_tail_split_kernel<false>, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, a);
+    timing_end(MSMP_K_NODE_UPDATE, (hipStream_t)stream);
+    return check_launch("node_tail_split_kernel");
 }
 
 extern "C" int msmp_node_update_f32(const float* h, const float* agg, const float* vars, int64_t n_nodes, int nv,

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include "msmp_pde.h"
 
+int msmp_tune_get(const char* key);    // current value of a msmp_tune switch ("split", "tail"); library-internal
+
 namespace msmp {
 
 constexpr int H = MSMP_HIDDEN;          // hidden width
@@ -12,6 +14,7 @@ constexpr int KC = 32;                  // k-chunk of a weight matrix staged thr
 constexpr int LDW = 36;                 // LDS row stride (dwords) of a staged chunk: 4*odd, so the
                                         // 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots
 constexpr int CHUNK_FLOATS = H * KC;    // one packed chunk: [128 out][32 k]
+constexpr int VAR_SLOT_FLOATS = 2 * 4 * 64 * 8 / 2;   // [2 k-steps][4 row tiles][64 lanes][8 halfs]
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -23,13 +26,15 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 //   w3 (8 chunks: h | agg columns of update_net_1) | w4 (4 chunks) | b1 b2 b3 b4 ([128] each) |
 //   w3v [128][MSMP_MAX_VARS] (variables columns of update_net_1) |
 //   w3s (8 split chunks, natural k order) | w4s (4, acc order) | scales [8]: 2^s of w1..w4, then 2^-s of w1..w4 |
+//   w3vh (the variables columns as two K=16 fp16 "slot" fragments per row tile, see var_slot_* in mfma_tiles.h) |
+//   w4t (4 split chunks, acc order, fragment row of (tile T, lane c) = W4 row 4 c + T: the transposed node tail's B operand) |
 //   w1 (nc1 chunks: h_i | h_j | u_i-u_j, p_i-p_j, vars_i, 0-pad) | w2 (4 chunks) |
 //   w1s (nc1 split chunks, natural) | w2s (4, acc order)
 // w4 directly follows w3 and w2 directly follows w1 (also in the split copies): the staging pipeline
 // prefetches across the seam.
 struct PackedLayout {
     int nc1;        // chunks of W1 (4 h_i + 4 h_j + tail chunks)
-    int64_t w3, w4, b1, b2, b3, b4, w3v, w3s, w4s, scales, w1, w2, w1s, w2s, total;
+    int64_t w3, w4, b1, b2, b3, b4, w3v, w3s, w4s, scales, w3vh, w4t, w1, w2, w1s, w2s, total;
 };
 
 __host__ __device__ inline int tail_chunks(int tw, int nv) { return (tw + 1 + nv + KC - 1) / KC; }
@@ -48,6 +53,8 @@ __host__ __device__ inline PackedLayout packed_layout(int tw, int nv) {
     L.w3s = o; o += 8 * CHUNK_FLOATS;
     L.w4s = o; o += 4 * CHUNK_FLOATS;
     L.scales = o; o += 8;
+    L.w3vh = o; o += VAR_SLOT_FLOATS;
+    L.w4t = o; o += 4 * CHUNK_FLOATS;
     L.w1 = o; o += (int64_t)L.nc1 * CHUNK_FLOATS;
     L.w2 = o; o += 4 * CHUNK_FLOATS;
     L.w1s = o; o += (int64_t)L.nc1 * CHUNK_FLOATS;

@@ -99,6 +99,8 @@ def test_pack_layer_layout(mp):
         w3s = sh(blob[o:o + 8 * 4096]); o += 8 * 4096
         w4s = sh(blob[o:o + 4 * 4096]); o += 4 * 4096
         scales = blob[o:o + 8]; o += 8
+        w3vh = blob[o:o + 2048].view(np.float16).reshape(2, 4, 64, 8).astype(np.float64); o += 2048   # [k-step][T][lane][j]
+        w4t = sh(blob[o:o + 4 * 4096]); o += 4 * 4096
         w1 = blob[o:o + nc1 * 4096].reshape(nc1, H, 32); o += nc1 * 4096
         w2 = blob[o:o + 4 * 4096].reshape(4, H, 32); o += 4 * 4096
         w1s = sh(blob[o:o + nc1 * 4096]); o += nc1 * 4096
@@ -106,6 +108,13 @@ def test_pack_layer_layout(mp):
         assert o == blob.size
         for i, k in enumerate(('message_net_1.0.weight', 'message_net_2.0.weight', 'update_net_1.0.weight', 'update_net_2.0.weight')):
             assert 16 <= np.abs(sd[k]).max() * scales[i] < 32 and scales[i] * scales[4 + i] == 1.0    # exact powers of two
+        # variable slot fragments: slots [0,8) and [8,16) carry w_hi, [16,24) w_lo, [24,32) zero; hi + lo = w * 2^s3
+        wv = sd['update_net_1.0.weight'][:, 2 * H:].astype(np.float64) * scales[2]
+        for T_ in range(4):
+            rows = 32 * T_ + np.arange(32)
+            hi0, hi1, lo, z = w3vh[0, T_, :32], w3vh[0, T_, 32:], w3vh[1, T_, :32], w3vh[1, T_, 32:]
+            assert np.array_equal(hi0, hi1) and not z.any() and not hi0[:, nv:].any() and not lo[:, nv:].any()
+            assert np.abs(hi0[:, :nv] + lo[:, :nv] - wv[rows]).max() <= 2.0 ** -21 * np.abs(wv).max()
         un = lambda c: np.transpose(c, (1, 0, 2)).reshape(H, -1)
         k1 = 2 * H + tw + 1 + nv
         assert np.array_equal(un(w1)[:, :k1], sd['message_net_1.0.weight']) and not un(w1)[:, k1:].any()
@@ -132,6 +141,9 @@ def test_pack_layer_layout(mp):
         tol = lambda ref: 2.0 ** -22 * np.abs(ref).max() + 1e-9
         assert np.abs(unsplit(w3s, False) * scales[6] - sd['update_net_1.0.weight'][:, :2 * H]).max() < tol(sd['update_net_1.0.weight'])
         assert np.abs(unsplit(w4s, True) * scales[7] - sd['update_net_2.0.weight']).max() < tol(sd['update_net_2.0.weight'])
+        # w4t: the same matrix with fragment row 32 T + c holding W4 row 4 c + T (the transposed node tail's B operand)
+        perm = np.array([4 * (r_ % 32) + r_ // 32 for r_ in range(H)])
+        assert np.abs(unsplit(w4t, True) * scales[7] - sd['update_net_2.0.weight'][perm]).max() < tol(sd['update_net_2.0.weight'])
         assert np.abs(unsplit(w1s, False)[:, :k1] * scales[4] - sd['message_net_1.0.weight']).max() < tol(sd['message_net_1.0.weight'])
         assert np.abs(unsplit(w2s, True) * scales[5] - sd['message_net_2.0.weight']).max() < tol(sd['message_net_2.0.weight'])
 
@@ -255,6 +267,47 @@ def test_layer_pieces_vs_oracle(mp, tw, nv, sizes, shuffle):
     ref = (1 - tau) * h64 + tau * O.swish(O.instance_norm(m_pre.double().cpu().numpy(), batch))
     err = np.abs(y.double().cpu().numpy() - ref).max()
     assert err < 5e-6, f'gate_blend {err}'
+
+
+@pytest.mark.parametrize('nv,sizes', [(2, [100, 100, 37, 1, 64]), (3, [128, 5, 90, 127]), (1, [2, 3, 33])])
+def test_node_tail_vs_oracle(mp, nv, sizes):
+    """Fused node tail (update head(s) + InstanceNorm + gated blend in one launch, graphs <= 128 nodes) against the
+    oracle's piecewise restatement; larger graphs are refused (the layer entry point then chains the pieces)."""
+    from msmp_pde_amd._lib import check, ptr, current_stream
+    L = mp.lib()
+    tw = 25
+    rng = np.random.default_rng(1000 + nv)
+    n = sum(sizes)
+    batch = np.repeat(np.arange(len(sizes)), sizes)
+    gptr = dev(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32))
+    h, _, _, var = layer_inputs(rng, n, tw, nv)
+    aggs = [rng.standard_normal((n, H)).astype(np.float32) for _ in range(2)]
+    sds = [rand_layer_sd(rng, tw, nv, scale=2.0) for _ in range(2)]
+    ps = [O.layer_params({k: v.astype(np.float64) for k, v in sd.items()}, '') for sd in sds]
+    blobs = [pack(mp, sd, tw, nv) for sd in sds]
+    h64, var64 = h.astype(np.float64), var.astype(np.float64)
+    dh, dvar, dagg = dev(h), dev(var), [dev(a) for a in aggs]
+    st = current_stream()
+    pre = lambda k, lin: O.instance_norm(O.node_update(ps[k], h64, aggs[k].astype(np.float64), var64, lin), batch)
+    # InstanceNorm over a 2- or 3-node graph divides by a standard deviation that can be tiny: fp32 rounding of the
+    # pre-norm values is amplified there, so those cases check masking / ragged handling at a looser bound
+    tol = 5e-6 if min(s_ for s_ in sizes if s_ > 1) >= 30 else 2e-4
+    out = torch.full((n, H), float('nan'), device='cuda')
+    check(L.msmp_node_tail_f32(ptr(dh), ptr(dagg[0]), ptr(dagg[1]), ptr(dvar), ptr(gptr), n, len(sizes), max(sizes), nv,
+                               ptr(blobs[0]), ptr(blobs[1]), 1, 1e-5, ptr(out), st), 'tail gated')
+    tau = O.sigmoid(pre(1, True))
+    ref = (1 - tau) * h64 + tau * O.swish(pre(0, True))
+    err = np.abs(out.double().cpu().numpy() - ref).max()
+    assert err < tol, f'gated tail {err}'
+    for mode, lin in ((1, True), (0, False)):
+        out = torch.full((n, H), float('nan'), device='cuda')
+        check(L.msmp_node_tail_f32(ptr(dh), ptr(dagg[0]), None, ptr(dvar), ptr(gptr), n, len(sizes), max(sizes), nv,
+                                   ptr(blobs[0]), None, mode, 1e-5, ptr(out), st), 'tail plain')
+        err = np.abs(out.double().cpu().numpy() - pre(0, lin)).max()
+        assert err < tol, f'plain tail mode {mode}: {err}'
+    rc = L.msmp_node_tail_f32(ptr(dh), ptr(dagg[0]), None, ptr(dvar), ptr(gptr), n, len(sizes), 129, nv, ptr(blobs[0]), None, 1,
+                              1e-5, ptr(out), st)
+    assert rc != 0 and b'128' in L.msmp_last_error()
 
 
 @pytest.mark.parametrize('cls,lin', [('GNN_Layer', False), ('GNN_LayerLin', True)])
