@@ -773,7 +773,6 @@ __device__ __forceinline__ void lem_ws_publish(const f32x16& st, half8* area, in
 
 // packed fp32 arithmetic (two values per instruction at the single-value issue cost); the compiler scalarises most
 // <2 x float> expressions, so the activation pipeline names the instructions
-using half2 = __attribute__((ext_vector_type(2))) _Float16;
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
     f32x2 d;
     asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -798,14 +797,6 @@ __device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) {  // c - a 
     f32x2 d;
     asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
-}
-// lo = fp16(x - float(hi)) for a pair, one mixed-precision FMA per value
-__device__ __forceinline__ half2 split_lo_pair(half2 hi, f32x2 x) {
-    half2 lo;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : "=&v"(lo) : "v"(hi), "v"(x[0]), "v"(x[1]));
-    return lo;
 }
 __device__ __forceinline__ float vmin(float a, float b) {            // bare v_min_f32 (fminf adds a canonicalising v_max)
     float d;

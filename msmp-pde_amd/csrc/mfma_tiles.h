@@ -100,12 +100,29 @@ __device__ __forceinline__ void acc_init_bias(const float* __restrict__ bias, in
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int SPLIT_CHUNK_FLOATS = 4096;      // 16 KB, same footprint as an fp32 chunk
 
+using half2 = __attribute__((ext_vector_type(2))) _Float16;
+// lo = fp16(x - float(hi)) for a pair: one mixed-precision FMA per value (x - hi is exact in fp32, so this equals the
+// convert-back / subtract / convert sequence bit for bit, in 2 instructions instead of 5).  Inline asm is invisible to the
+// compiler's hazard recogniser: x and hi must not be the direct result of an MFMA or a transcendental instruction
+// (every caller passes loaded values or the output of ordinary VALU arithmetic).
+__device__ __forceinline__ half2 split_lo_pair(half2 hi, f32x2 x) {
+    half2 lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo) : "v"(hi), "v"(x[0]), "v"(x[1]));
+    return lo;
+}
+
 __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const _Float16 h = (_Float16)x[j];
-        hi[j] = h;
-        lo[j] = (_Float16)(x[j] - (float)h);
+    for (int j = 0; j < 8; j += 2) {
+        const f32x2 v = {x[j], x[j + 1]};
+        const half2 h = __builtin_convertvector(v, half2);
+        const half2 l = split_lo_pair(h, v);
+        hi[j] = h[0];
+        hi[j + 1] = h[1];
+        lo[j] = l[0];
+        lo[j + 1] = l[1];
     }
 }
 

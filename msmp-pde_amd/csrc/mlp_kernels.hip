@@ -82,6 +82,31 @@ __device__ __forceinline__ void edge_gather(const EdgeArgs& a, int c, int i, int
 //               are rounded (validated against the float64 oracle with the same bars).
 // SPLIT (with FACT): message_net_2 on the fp16 matrix pipe with the 2-way fp16 split of mfma_tiles.h (fp32-class
 //               accuracy, 5.3x fewer matrix-pipe cycles); weights from the split chunks `w2s` of the blob.
+// Phase profile of the tail / edge kernels (build with MSMP_PROF=1 in the environment of build.py; scripts/prof_tail.py reads it):
+// per-workgroup cycle sums of wave 0, kept in scalar registers and added to g_prof once at the end.
+#if MSMP_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_DECL long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tp = __builtin_readcyclecounter();
+#define PROF_ARGS , long long& tp, long long (&pacc)[12]
+#define PROF_PASS , tp, pacc
+#define PROF_MARK(i) do { const long long t_ = __builtin_readcyclecounter(); pacc[i] += t_ - tp; tp = t_; } while (0)
+#define PROF_FLUSH if (tid == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_prof[i_], (unsigned long long)pacc[i_]);
+#if MSMP_PROF_EDGE
+#define PROF_EDGE(i) PROF_MARK(i)
+#define PROF_EDGE_FLUSH PROF_FLUSH
+#endif
+#else
+#define PROF_DECL
+#define PROF_ARGS
+#define PROF_PASS
+#define PROF_MARK(i)
+#define PROF_FLUSH
+#endif
+#ifndef PROF_EDGE
+#define PROF_EDGE(i)
+#define PROF_EDGE_FLUSH
+#endif
+
 template <int NB, bool FUSE, bool FACT, bool SPLIT>
 __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
     static_assert(!SPLIT || FACT, "the split path is built for the factorised kernel");
@@ -110,6 +135,7 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
         nj[nb] = a.col[ec];
     }
 
+    PROF_DECL
     f32x16 z[4][NB];
     WStage ws;
     int par;                     // LDS buffer holding W2 chunk 0
@@ -192,6 +218,7 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
             }
         };
         gather_tile(0);
+        PROF_EDGE(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (t < 3) wstage_load(ws, a.w2s + (size_t)(t + 1) * SPLIT_CHUNK_FLOATS, tid);
@@ -202,14 +229,18 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int m = 0; m < 4; ++m) zt[nb][4 * q + m] = swishf(pq[nb][q][m] + pq[nb][4 + q][m]);
+            PROF_EDGE(1);
             if (t < 3) gather_tile(t + 1);          // in flight during this chunk's matrix work
             half8 bhi[NB][2], blo[NB][2];
             split_acc_tile<NB>(zt, bhi, blo);
+            PROF_EDGE(2);
             mma_chunk_split<NB>(lds + (t & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, y);
+            PROF_EDGE(3);
             if (t < 3) {
                 wstage_store_linear(ws, lds + ((t + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
                 __syncthreads();
             }
+            PROF_EDGE(4);
         }
         const float inv2 = a.scales[5];
 #pragma unroll
@@ -265,9 +296,11 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
             r0a[k] = in ? a.rowptr[node] - (int)tile_e0 : 0;
             r1a[k] = in ? a.rowptr[node + 1] - (int)tile_e0 : 0;
         }
+        PROF_EDGE(5);
 #pragma unroll
         for (int R = 0; R < 4 / TPR; ++R) {
             __syncthreads();     // previous readers of lds (W2 chunk 3 / previous round) are done
+            PROF_EDGE(6);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 float* o = lds + (wave * 32 * NB + 32 * nb + c) * LDR + 4 * hh;
@@ -281,7 +314,9 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
                         *reinterpret_cast<f32x4*>(o + 32 * tt + 8 * q) = v;
                     }
             }
+            PROF_EDGE(7);
             __syncthreads();
+            PROF_EDGE(8);
             int k = 0;
             for (int node = tile_n0 + slot; node < tile_n1; node += NSLOT, ++k) {
                 int r0, r1;
@@ -302,8 +337,10 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
                 const float inv = 1.0f / (float)max(r1 - r0, 1);
                 *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + CPR * R + 4 * cq) = sum * inv;
             }
+            PROF_EDGE(9);
         }
     }
+    PROF_EDGE_FLUSH
 }
 
 template <int NB, bool FUSE, bool FACT, bool SPLIT = false>
@@ -815,23 +852,6 @@ __global__ __launch_bounds__(256, 2) void node_update_split_kernel(NodeSplitArgs
 // The variables columns are two fp16 slot MFMAs (var_slot_frags).  Against node_update x2 + gate_blend this reads
 // h, agg_main, agg_gate and writes h' (420 MB instead of 1050 MB at 2048 x 100 nodes).
 // ----------------------------------------------------------------------------------------------
-// Phase profile of the tail kernel (build with MSMP_PROF=1 in the environment of build.py; scripts/prof_tail.py reads it):
-// per-workgroup cycle sums of wave 0, kept in scalar registers and added to g_prof once at the end.
-#if MSMP_PROF
-__device__ unsigned long long g_prof[16];
-#define PROF_DECL long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tp = __builtin_readcyclecounter();
-#define PROF_ARGS , long long& tp, long long (&pacc)[12]
-#define PROF_PASS , tp, pacc
-#define PROF_MARK(i) do { const long long t_ = __builtin_readcyclecounter(); pacc[i] += t_ - tp; tp = t_; } while (0)
-#define PROF_FLUSH if (tid == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_prof[i_], (unsigned long long)pacc[i_]);
-#else
-#define PROF_DECL
-#define PROF_ARGS
-#define PROF_PASS
-#define PROF_MARK(i)
-#define PROF_FLUSH
-#endif
-
 struct TailArgs {
     const float* h;
     const float* agg[2];     // main, gate

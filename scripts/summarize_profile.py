@@ -47,7 +47,8 @@ lines = [f'# rocprofv3 summary `{tag}` (MI355X, bench.py default workload: E2 MS
 if bench:
     lines += [f"bench line of the traced run: {bench['value']:.2f} rollout-steps/s, {bench['ms_per_step']:.2f} ms/step; "
               f"edge_mlp avg launch {bench['roofline']['avg_launch_ms']:.3f} ms (HIP events) -> "
-              f"{bench['roofline']['achieved']:.1f} TFLOP/s = {100 * bench['roofline']['frac']:.1f} % of fp32 MFMA peak", '']
+              f"{bench['roofline']['achieved']:.1f} TFLOP/s fp32-equivalent = {100 * bench['roofline']['frac']:.1f} % of the roofline peak "
+              f"({bench['roofline']['peak']:.0f} TFLOP/s: {bench['roofline'].get('peak_note', 'dense fp32 MFMA peak')})", '']
 lines += [f'total kernel time in trace: {tot / 1e6:.1f} ms', '',
           '| kernel | calls | avg us | total ms | % |', '|---|---|---|---|---|']
 for r in rows[:25]:
