@@ -161,6 +161,10 @@ __global__ void pack_layer_split_kernel(PackArgs a) {
         const float w = a.w4[(size_t)(4 * (lane & 31) + T) * H + 32 * ch + split_k_acc(s, lane >> 5, j)] * sc[3];
         const _Float16 hi = (_Float16)w;
         out_t[p] = plane == 0 ? hi : (_Float16)(w - (float)hi);
+        // message_net_2 likewise, natural k order (its A operand is gathered from memory)
+        const float w2 = a.w2[(size_t)(4 * (lane & 31) + T) * H + 32 * ch + split_k_natural(s, lane >> 5, j)] * sc[1];
+        const _Float16 hi2 = (_Float16)w2;
+        reinterpret_cast<_Float16*>(a.out + L.w2t)[p] = plane == 0 ? hi2 : (_Float16)(w2 - (float)hi2);
     }
     // variables columns of update_net_1 as slot fragments (A operand: lane = row, slots 16 m + 8 h + j)
     _Float16* out_v = reinterpret_cast<_Float16*>(a.out + L.w3vh);

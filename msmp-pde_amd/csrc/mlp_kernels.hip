@@ -1173,6 +1173,9 @@ extern "C" int msmp_node_project_f32(const float* h, const float* u, const float
 static int g_edge_occ = 4;     // 4 waves per SIMD (128 registers) measured 5 % faster than 3 (134 registers)
 static int g_edge_nb = 0;    // tuning override (msmp_tune): 0 = automatic, 1 / 2 = force the tile size of the factorised kernel
 
+extern int g_edge_ws_waves;
+static int g_edge_ws = 0;    // 1: persistent weight-stationary message + mean kernel (max in-degree <= 32; msmp_tune "edge_ws");
+                             // measured equal to the streamed-weight kernel (2.43 vs 2.41 ms per step), so the latter stays the default
 static int g_tail = 1;       // fused node tail (msmp_node_tail_f32) inside msmp_mp_layer_f32; msmp_tune("tail", 0) chains the pieces
 int msmp_tune_get(const char* key) {
     if (!strcmp(key, "split")) return g_split;
@@ -1182,6 +1185,8 @@ int msmp_tune_get(const char* key) {
 
 extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "tail")) { g_tail = value; return MSMP_OK; }
+    if (key && !strcmp(key, "edge_ws")) { g_edge_ws = value; return MSMP_OK; }
+    if (key && !strcmp(key, "edge_ws_waves")) { g_edge_ws_waves = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_occ")) { g_edge_occ = value; return MSMP_OK; }
     if (key && !strcmp(key, "lem")) { g_lem_split = value; return MSMP_OK; }
@@ -1190,6 +1195,8 @@ extern "C" int msmp_tune(const char* key, int value) {
     return MSMP_ERR_ARG;
 }
 
+int msmp_launch_edge_ws(const float* P, const float* Q, const int32_t* rowptr, const int32_t* col, const int32_t* tgt, int64_t n_nodes,
+                        int max_in_degree, const float* w2t, const float* b2, const float* scales, float* agg, hipStream_t stream);
 static int edge_aggregate(const float* h, const float* u, const float* pos, const float* vars, const float* P, const float* Q,
                           const int32_t* rowptr, const int32_t* col, const int32_t* tgt, int64_t n_nodes, int64_t n_edges,
                           int max_in_degree, int tw, int nv, const float* packed, float* agg_out, msmp_stream_t stream,
@@ -1215,7 +1222,10 @@ static int edge_aggregate(const float* h, const float* u, const float* pos, cons
                packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, P, Q, nullptr, agg_out};
     const unsigned grid = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
     timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
-    if (P && edges_per_tile == 128 && g_split && g_edge_occ == 4) hipLaunchKernelGGL((edge_mlp_kernel_occ4<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (P && g_split && g_edge_ws && max_in_degree >= 1 && max_in_degree <= 32)
+        msmp_launch_edge_ws(P, Q, rowptr, col, tgt, n_nodes, max_in_degree, packed + L.w2t, packed + L.b2, packed + L.scales, agg_out,
+                            (hipStream_t)stream);
+    else if (P && edges_per_tile == 128 && g_split && g_edge_occ == 4) hipLaunchKernelGGL((edge_mlp_kernel_occ4<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (P && edges_per_tile == 128 && g_split) hipLaunchKernelGGL((edge_mlp_kernel_occ2<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (P && edges_per_tile == 128) hipLaunchKernelGGL((edge_mlp_kernel<1, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (P) hipLaunchKernelGGL((edge_mlp_kernel<2, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

@@ -28,13 +28,14 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 //   w3s (8 split chunks, natural k order) | w4s (4, acc order) | scales [8]: 2^s of w1..w4, then 2^-s of w1..w4 |
 //   w3vh (the variables columns as two K=16 fp16 "slot" fragments per row tile, see var_slot_* in mfma_tiles.h) |
 //   w4t (4 split chunks, acc order, fragment row of (tile T, lane c) = W4 row 4 c + T: the transposed node tail's B operand) |
+//   w2t (4 split chunks, natural k order, rows dealt the same way: the weight-stationary edge kernel's B operand) |
 //   w1 (nc1 chunks: h_i | h_j | u_i-u_j, p_i-p_j, vars_i, 0-pad) | w2 (4 chunks) |
 //   w1s (nc1 split chunks, natural) | w2s (4, acc order)
 // w4 directly follows w3 and w2 directly follows w1 (also in the split copies): the staging pipeline
 // prefetches across the seam.
 struct PackedLayout {
     int nc1;        // chunks of W1 (4 h_i + 4 h_j + tail chunks)
-    int64_t w3, w4, b1, b2, b3, b4, w3v, w3s, w4s, scales, w3vh, w4t, w1, w2, w1s, w2s, total;
+    int64_t w3, w4, b1, b2, b3, b4, w3v, w3s, w4s, scales, w3vh, w4t, w2t, w1, w2, w1s, w2s, total;
 };
 
 __host__ __device__ inline int tail_chunks(int tw, int nv) { return (tw + 1 + nv + KC - 1) / KC; }
@@ -55,6 +56,7 @@ __host__ __device__ inline PackedLayout packed_layout(int tw, int nv) {
     L.scales = o; o += 8;
     L.w3vh = o; o += VAR_SLOT_FLOATS;
     L.w4t = o; o += 4 * CHUNK_FLOATS;
+    L.w2t = o; o += 4 * CHUNK_FLOATS;
     L.w1 = o; o += (int64_t)L.nc1 * CHUNK_FLOATS;
     L.w2 = o; o += 4 * CHUNK_FLOATS;
     L.w1s = o; o += (int64_t)L.nc1 * CHUNK_FLOATS;
