@@ -164,6 +164,40 @@ class _SolverBase(nn.Module):
         return out.to(u_in.dtype)
 
 
+    def capture(self, data):
+        """hipGraph of `forward` for a fixed graph batch (inference): returns `step(data) -> prediction` that copies the
+        per-step inputs (`data.x`, `data.pos`) into static buffers and replays ONE graph launch instead of the ~60 kernel
+        launches of the eager forward (the rollout is launch-bound between its kernels: ~0.5 ms of a 7.4 ms step).  The
+        structure tensors (edge_index, batch, equation variables) are those of `data` at capture time."""
+        return _GraphedForward(self, data)
+
+
+class _GraphedForward:
+    def __init__(self, model, data):
+        import copy
+        assert not torch.is_grad_enabled(), 'capture() is for inference: wrap it in torch.no_grad()'
+        self.model = model
+        self.data = copy.copy(data)                       # shallow: shares edge_index / batch / variables / cached structure
+        self.data.x = data.x.clone()
+        self.data.pos = data.pos.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                     # warm-up on a side stream: weight packing, workspaces, CSR build
+            for _ in range(2):
+                model(self.data)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = model(self.data)
+
+    def __call__(self, data):
+        self.data.x.copy_(data.x)
+        self.data.pos.copy_(data.pos)
+        self.graph.replay()
+        return self.out.clone()
+
+
 class MP_PDE_Solver(_SolverBase):
     pass
 

@@ -158,6 +158,25 @@ def test_graph_sharding_is_exact(mp):
         assert (part - full[sl]).abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize('name,exp', [('MSMP-PDE', 'E2'), ('Gated2D', 'MSWG3')])
+def test_captured_rollout_step_is_bit_identical(mp, name, exp):
+    """Solver.capture(): the hipGraph replay of forward() gives the eager result bit for bit, also after the per-step
+    inputs (x, time position) have changed, i.e. the replay really reads the refreshed static buffers."""
+    torch.manual_seed(11)
+    case = synthetic_case(mp, exp, bsz=4, seed=9)
+    model = mp.MODEL_NAMES[name](case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=2).cuda().eval()
+    graph = case.graph.to('cuda')
+    with torch.no_grad():
+        ref = model(graph)
+        step = model.capture(graph)
+        assert torch.equal(step(graph), ref)
+        graph.x = ref.clone()
+        graph.pos[:, 0] += 0.25
+        ref2 = model(graph)
+        assert not torch.equal(ref2, ref)
+        assert torch.equal(step(graph), ref2)
+
+
 def test_fails_loudly_without_gpu_tensors(mp):
     case = synthetic_case(mp, 'E2', bsz=2, seed=1, device='cpu')
     model = mp.MP_PDE_Solver(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=1)
