@@ -18,7 +18,7 @@ SOURCES = {  # file -> extra flags
     'decoder_kernel.hip': [],
     'graph_kernels.hip': ['-ffp-contract=off'],   # float64 distance compares must round like the host's
 }
-PROF = {'1': ['-DMSMP_PROF=1'], 'edge': ['-DMSMP_PROF=1', '-DMSMP_PROF_EDGE=1']}.get(os.environ.get('MSMP_PROF', ''), [])     # phase counters in the tail kernel (scripts/prof_tail.py)
+PROF = {'1': ['-DMSMP_PROF=1'], 'edge': ['-DMSMP_PROF=1', '-DMSMP_PROF_EDGE=1'], 'proj': ['-DMSMP_PROF=1', '-DMSMP_PROF_PROJ=1']}.get(os.environ.get('MSMP_PROF', ''), [])     # phase counters in the tail kernel (scripts/prof_tail.py)
 COMMON = PROF + ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
           '-fvisibility=hidden', '-fvisibility-inlines-hidden',
           '-I', os.path.join(ROOT, 'include'), '-I', CSRC]

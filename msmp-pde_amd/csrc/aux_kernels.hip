@@ -166,6 +166,16 @@ __global__ void pack_layer_split_kernel(PackArgs a) {
         const _Float16 hi2 = (_Float16)w2;
         reinterpret_cast<_Float16*>(a.out + L.w2t)[p] = plane == 0 ? hi2 : (_Float16)(w2 - (float)hi2);
     }
+    // message_net_1 with dealt rows (natural k order, zero padded past k1): node_proj's transposed B operand
+    _Float16* out_w1t = reinterpret_cast<_Float16*>(a.out + L.w1t);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < (int64_t)L.nc1 * 8192; p += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(p >> 13), idx = (int)(p & 8191);
+        const int j = idx & 7, lane = (idx >> 3) & 63, plane = (idx >> 9) & 1, T = (idx >> 10) & 3, s = (idx >> 12) & 1;
+        const int k = 32 * ch + split_k_natural(s, lane >> 5, j);
+        const float w = k < k1 ? a.w1[(size_t)(4 * (lane & 31) + T) * k1 + k] * sc[0] : 0.f;
+        const _Float16 hi = (_Float16)w;
+        out_w1t[p] = plane == 0 ? hi : (_Float16)(w - (float)hi);
+    }
     // variables columns of update_net_1 as slot fragments (A operand: lane = row, slots 16 m + 8 h + j)
     _Float16* out_v = reinterpret_cast<_Float16*>(a.out + L.w3vh);
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < 2 * VAR_SLOT_FLOATS; p += (int64_t)gridDim.x * blockDim.x) {

@@ -106,6 +106,15 @@ __device__ unsigned long long g_prof[16];
 #define PROF_EDGE(i)
 #define PROF_EDGE_FLUSH
 #endif
+#if MSMP_PROF_PROJ
+#define PROF_PROJ(i) PROF_MARK(i)
+#define PROF_PROJ_DECL PROF_DECL
+#define PROF_PROJ_FLUSH PROF_FLUSH
+#else
+#define PROF_PROJ(i)
+#define PROF_PROJ_DECL
+#define PROF_PROJ_FLUSH
+#endif
 
 template <int NB, bool FUSE, bool FACT, bool SPLIT>
 __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
@@ -629,10 +638,31 @@ __device__ __forceinline__ void bfrag_read(const _Float16* tile, int node_local,
 
 struct ProjSplitArgs {
     ProjArgs b;
-    const float* w1s;     // nc1 split chunks (natural order)
+    const float* w1s;     // nc1 split chunks, natural k order, rows dealt round-robin (packed_layout().w1t)
     const float* scales;  // [8]
 };
 
+// acc[T] += A B for the 32 k of one split chunk with the operands swapped: A = the caller's fragments (a node / edge per lane),
+// B = the weight chunk in LDS, so acc is [32 items][channel = lane] (the transposed form of mma_chunk_split<1>)
+__device__ __forceinline__ void mma_chunk_split_t(const float* wl, int lane, const half8 (&ahi)[1][2], const half8 (&alo)[1][2],
+                                                  f32x16 (&acc)[4]) {
+    const half8* w = reinterpret_cast<const half8*>(wl) + lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            const half8 whi = w[((s * 4 + T) * 2 + 0) * 64];
+            const half8 wlo = w[((s * 4 + T) * 2 + 1) * 64];
+            acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0][s], wlo, acc[T], 0, 0, 0);
+            acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[0][s], whi, acc[T], 0, 0, 0);
+            acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0][s], whi, acc[T], 0, 0, 0);
+        }
+}
+
+// P and Q are computed TRANSPOSED (node fragments as A operand, the row-dealt w1t chunks as B): the accumulators hold
+// [32 nodes of the wave][channel 4 c + T], so a lane stores 16 consecutive bytes of whole 512-byte rows (16 stores per
+// matrix instead of 32 quarter-line pieces).  The tail chunk ([u, pos, vars] columns) is read with unconditional, clamped
+// loads and selected afterwards: predicated per-element loads compiled into serially waited-for blocks (27 % of the kernel).
 __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs sa) {
     __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS + 2 * BTILE_FLOATS];
     float* wbuf = lds;
@@ -645,10 +675,26 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs s
     const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
     const int nl = wave * 32 + c;
     const float sc = sa.scales[0], inv = sa.scales[4];
+    PROF_PROJ_DECL
 
-    f32x16 p[4][1], qa[4][1];
-    acc_init_bias_scaled<1>(a.b1, sc, hh, p);
-    acc_zero<1>(qa);
+    f32x16 p[4], qa[4];
+    {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b1 + 4 * c) * sc;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[T][r] = bv[T]; qa[T][r] = 0.f; }
+    }
+    // tail features of this lane's node, k = 16 s + 8 hh + j: [u (tw), pos, vars (nv), 0...]; loads first, selection later
+    float tu[16], tv[16];
+    const float* un = a.u + (size_t)nc * a.tw;
+    const float tpos = a.pos[nc];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = 16 * (i >> 3) + 8 * hh + (i & 7);
+        tu[i] = un[min(k, a.tw - 1)];
+        tv[i] = a.vars[(size_t)nc * a.nv + min(max(k - a.tw - 1, 0), a.nv - 1)];
+    }
     // step st = 0..7 uses weight chunk (st & 1 ? 4 : 0) + (st >> 1) (P then Q of the same h chunk st >> 1)
     WStage ws;
     BStage bs;
@@ -657,6 +703,7 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs s
     wstage_store_linear(ws, wbuf, tid);
     bstage_store(bs, bbuf, tid);
     __syncthreads();
+    PROF_PROJ(0);
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
         const int nxt = st + 1;                                   // next step's weight chunk (8 = first tail chunk)
@@ -665,16 +712,27 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs s
         if ((st & 1) && st < 7) bstage_load(bs, a.h, n0, a.n_nodes, 32 * ((st >> 1) + 1), tid);
         half8 bhi[1][2], blo[1][2];
         bfrag_read(bbuf + ((st >> 1) & 1) * 128 * BROW, nl, hh, bhi, blo);
-        if (st & 1) mma_chunk_split<1>(wbuf + (st & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, qa);
-        else mma_chunk_split<1>(wbuf + (st & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, p);
+        PROF_PROJ(1);
+        if (st & 1) mma_chunk_split_t(wbuf + (st & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, qa);
+        else mma_chunk_split_t(wbuf + (st & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, p);
+        PROF_PROJ(2);
         wstage_store_linear(ws, wbuf + ((st + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
         if ((st & 1) && st < 7) bstage_store(bs, bbuf + (((st >> 1) + 1) & 1) * 128 * BROW, tid);
+        PROF_PROJ(3);
         __syncthreads();
+        PROF_PROJ(4);
     }
-    // tail chunks 8.. : [u_n, p_n, v_n] for P and [-u_n, -p_n, 0] for Q (per-lane scalar loads; 1-2 chunks)
-    const float* un = a.u + (size_t)nc * a.tw;
+    // tail chunks 8.. : [u_n, p_n, v_n] for P and [-u_n, -p_n, 0] for Q (1 chunk for tw <= 25 + ..., 2 for tw = 50)
     for (int ch = 8; ch < a.nc1; ++ch) {
         if (ch + 1 < a.nc1) wstage_load(ws, sa.w1s + (size_t)(ch + 1) * SPLIT_CHUNK_FLOATS, tid);
+        if (ch > 8) {                   // second tail chunk (tw = 50): fetch its columns now
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = 32 * (ch - 8) + 16 * (i >> 3) + 8 * hh + (i & 7);
+                tu[i] = un[min(k, a.tw - 1)];
+                tv[i] = a.vars[(size_t)nc * a.nv + min(max(k - a.tw - 1, 0), a.nv - 1)];
+            }
+        }
         half8 phi[1][2], plo[1][2], qhi[1][2], qlo[1][2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -682,35 +740,43 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs s
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = 32 * (ch - 8) + 16 * s + 8 * hh + j;
-                float x = 0.f, y = 0.f;
-                if (k < a.tw) { x = un[k]; y = -x; }
-                else if (k == a.tw) { x = a.pos[nc]; y = -x; }
-                else if (k <= a.tw + a.nv) x = a.vars[(size_t)nc * a.nv + (k - a.tw - 1)];
+                const float x = k < a.tw ? tu[8 * s + j] : k == a.tw ? tpos : k <= a.tw + a.nv ? tv[8 * s + j] : 0.f;
                 vp[j] = x;
-                vq[j] = y;
+                vq[j] = k <= a.tw ? -x : 0.f;
             }
             split8(vp, phi[0][s], plo[0][s]);
             split8(vq, qhi[0][s], qlo[0][s]);
         }
-        mma_chunk_split<1>(wbuf + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, phi, plo, p);
-        mma_chunk_split<1>(wbuf + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, qhi, qlo, qa);
+        PROF_PROJ(5);
+        mma_chunk_split_t(wbuf + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, phi, plo, p);
+        mma_chunk_split_t(wbuf + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, qhi, qlo, qa);
         if (ch + 1 < a.nc1) wstage_store_linear(ws, wbuf + ((ch + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
         __syncthreads();
+        PROF_PROJ(6);
     }
-    if (n < a.n_nodes) {
-        float* po = a.P + (size_t)n * H + 4 * hh;
-        float* qo = a.Q + (size_t)n * H + 4 * hh;
+    // rows of this lane: node n0 + 32 wave + acc_row(r, hh), channels 4 c .. 4 c + 3
+    const size_t base = ((size_t)n0 + wave * 32 + 4 * hh) * H + 4 * c;
+    const long lim = a.n_nodes - n0 - wave * 32 - 4 * hh;
+    if (n0 + wave * 32 + 32 <= a.n_nodes) {         // wave-uniform common path: no per-row predication
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
+        for (int r = 0; r < 16; ++r) {
+            const size_t o = base + (size_t)((r & 3) + 8 * (r >> 2)) * H;
+            *reinterpret_cast<f32x4*>(a.P + o) = f32x4{p[0][r], p[1][r], p[2][r], p[3][r]} * inv;
+            *reinterpret_cast<f32x4*>(a.Q + o) = f32x4{qa[0][r], qa[1][r], qa[2][r], qa[3][r]} * inv;
+        }
+    } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v, w;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) { v[m] = p[T][0][4 * q + m] * inv; w[m] = qa[T][0][4 * q + m] * inv; }
-                *reinterpret_cast<f32x4*>(po + 32 * T + 8 * q) = v;
-                *reinterpret_cast<f32x4*>(qo + 32 * T + 8 * q) = w;
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2);
+            if (row < lim) {
+                const size_t o = base + (size_t)row * H;
+                *reinterpret_cast<f32x4*>(a.P + o) = f32x4{p[0][r], p[1][r], p[2][r], p[3][r]} * inv;
+                *reinterpret_cast<f32x4*>(a.Q + o) = f32x4{qa[0][r], qa[1][r], qa[2][r], qa[3][r]} * inv;
             }
+        }
     }
+    PROF_PROJ(7);
+    PROF_PROJ_FLUSH
 }
 
 // node_update keeps the per-lane row gather: with 50 KB less LDS three workgroups share a CU, which measured
@@ -1162,7 +1228,7 @@ extern "C" int msmp_node_project_f32(const float* h, const float* u, const float
     const unsigned grid = (unsigned)((n_nodes + 127) / 128);
     timing_begin(MSMP_K_NODE_PROJ, (hipStream_t)stream);
     if (g_split) {
-        ProjSplitArgs sa{a, packed + L.w1s, packed + L.scales};
+        ProjSplitArgs sa{a, packed + L.w1t, packed + L.scales};
         hipLaunchKernelGGL(node_proj_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, sa);
     } else
         hipLaunchKernelGGL(node_proj_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

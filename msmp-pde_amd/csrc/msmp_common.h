@@ -30,12 +30,13 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 //   w4t (4 split chunks, acc order, fragment row of (tile T, lane c) = W4 row 4 c + T: the transposed node tail's B operand) |
 //   w2t (4 split chunks, natural k order, rows dealt the same way: the weight-stationary edge kernel's B operand) |
 //   w1 (nc1 chunks: h_i | h_j | u_i-u_j, p_i-p_j, vars_i, 0-pad) | w2 (4 chunks) |
-//   w1s (nc1 split chunks, natural) | w2s (4, acc order)
+//   w1s (nc1 split chunks, natural) | w2s (4, acc order) |
+//   w1t (nc1 split chunks, natural, rows dealt round-robin like w4t: node_proj computes P / Q transposed)
 // w4 directly follows w3 and w2 directly follows w1 (also in the split copies): the staging pipeline
 // prefetches across the seam.
 struct PackedLayout {
     int nc1;        // chunks of W1 (4 h_i + 4 h_j + tail chunks)
-    int64_t w3, w4, b1, b2, b3, b4, w3v, w3s, w4s, scales, w3vh, w4t, w2t, w1, w2, w1s, w2s, total;
+    int64_t w3, w4, b1, b2, b3, b4, w3v, w3s, w4s, scales, w3vh, w4t, w2t, w1, w2, w1s, w2s, w1t, total;
 };
 
 __host__ __device__ inline int tail_chunks(int tw, int nv) { return (tw + 1 + nv + KC - 1) / KC; }
@@ -61,6 +62,7 @@ __host__ __device__ inline PackedLayout packed_layout(int tw, int nv) {
     L.w2 = o; o += 4 * CHUNK_FLOATS;
     L.w1s = o; o += (int64_t)L.nc1 * CHUNK_FLOATS;
     L.w2s = o; o += 4 * CHUNK_FLOATS;
+    L.w1t = o; o += (int64_t)L.nc1 * CHUNK_FLOATS;
     L.total = o;
     return L;
 }

@@ -106,6 +106,7 @@ def test_pack_layer_layout(mp):
         w2 = blob[o:o + 4 * 4096].reshape(4, H, 32); o += 4 * 4096
         w1s = sh(blob[o:o + nc1 * 4096]); o += nc1 * 4096
         w2s = sh(blob[o:o + 4 * 4096]); o += 4 * 4096
+        w1t = sh(blob[o:o + nc1 * 4096]); o += nc1 * 4096
         assert o == blob.size
         for i, k in enumerate(('message_net_1.0.weight', 'message_net_2.0.weight', 'update_net_1.0.weight', 'update_net_2.0.weight')):
             assert 16 <= np.abs(sd[k]).max() * scales[i] < 32 and scales[i] * scales[4 + i] == 1.0    # exact powers of two
@@ -146,6 +147,7 @@ def test_pack_layer_layout(mp):
         perm = np.array([4 * (r_ % 32) + r_ // 32 for r_ in range(H)])
         assert np.abs(unsplit(w4t, True) * scales[7] - sd['update_net_2.0.weight'][perm]).max() < tol(sd['update_net_2.0.weight'])
         assert np.abs(unsplit(w2t, False) * scales[5] - sd['message_net_2.0.weight'][perm]).max() < tol(sd['message_net_2.0.weight'])
+        assert np.abs(unsplit(w1t, False)[:, :k1] * scales[4] - sd['message_net_1.0.weight'][perm]).max() < tol(sd['message_net_1.0.weight'])
         assert np.abs(unsplit(w1s, False)[:, :k1] * scales[4] - sd['message_net_1.0.weight']).max() < tol(sd['message_net_1.0.weight'])
         assert np.abs(unsplit(w2s, True) * scales[5] - sd['message_net_2.0.weight']).max() < tol(sd['message_net_2.0.weight'])
 

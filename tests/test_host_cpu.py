@@ -36,7 +36,7 @@ def test_cabi_exports_every_declared_symbol(mp):
     for name in declared:
         assert hasattr(L, name), name
     assert L.msmp_version() >= 100
-    assert L.msmp_packed_layer_floats(25, 2) == 2 * (12 + 13) * 4096 + 4 * 128 + 128 * 8 + 8 + 2048 + 8 * 4096     # fp32 chunks + fp16-split copies + biases + w3v + scales + variable slot fragments + w4t + w2t
+    assert L.msmp_packed_layer_floats(25, 2) == (2 * (12 + 13) + 9) * 4096 + 4 * 128 + 128 * 8 + 8 + 2048 + 8 * 4096     # fp32 chunks + fp16-split copies + biases + w3v + scales + variable slot fragments + w4t + w2t (+ w1t: 9 more chunks)
     assert L.msmp_packed_layer_floats(25, 99) == -1
 
 
