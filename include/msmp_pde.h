@@ -237,6 +237,17 @@ int msmp_decoder2d_f32(const float* hd, const float* u, int64_t n_nodes, int tw,
                        const float* b1, const float* w2, const float* b2, float dt, float* out,
                        msmp_stream_t stream);
 
+/* Two-layer node MLP  out = Swish(W2 Swish(W1 x + b1) + b2)  in one launch: the `embedding_mlp` encoder of the LEM-free
+ * solver classes (experiments/models_gnn.py:196-201 called at :269-270; models_gnn2D.py:66-71 called at :119-120).
+ * w1 [128, k_in] (k_in = in_features of the first Linear <= 128), w2 [128,128], b* [128], reference layout.
+ * x: [N, msmp_mlp2_input_stride(k_in)] float32, the concatenated node input [u | pos_x | variables] with rows zero-padded
+ * to that stride (a multiple of 32 floats); out [N,128]. */
+int64_t msmp_packed_mlp2_floats(int k_in);
+int msmp_mlp2_input_stride(int k_in);
+int msmp_pack_mlp2_f32(const float* w1, const float* b1, const float* w2, const float* b2, int k_in, float* packed_out,
+                       msmp_stream_t stream);
+int msmp_mlp2_swish_f32(const float* x, int64_t n_nodes, int k_in, const float* packed, float* out, msmp_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * In-library kernel timing (measurement aid for bench.py; off by default, not part of the data path)
  * When enabled, every launch of the named kernel family is bracketed by hipEvents recorded on the

@@ -43,6 +43,10 @@ SIGNATURES = {
     'msmp_decoder_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     'msmp_decoder2d_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     'msmp_node_tail_f32': (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    'msmp_packed_mlp2_floats': (c_int64, [c_int]),
+    'msmp_mlp2_input_stride': (c_int, [c_int]),
+    'msmp_pack_mlp2_f32': (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_void_p]),
+    'msmp_mlp2_swish_f32': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'msmp_timing_enable': (c_int, [c_int]),
     'msmp_timing_reset': (c_int, []),
     'msmp_timing_read': (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),

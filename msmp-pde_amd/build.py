@@ -15,6 +15,7 @@ SOURCES = {  # file -> extra flags
     # MFMA results stay in VGPRs (the activations read them with VALU; the stationary weights take the AGPRs)
     'lem_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
     'edge_ws_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
+    'mlp2_kernel.hip': [],
     'decoder_kernel.hip': [],
     'graph_kernels.hip': ['-ffp-contract=off'],   # float64 distance compares must round like the host's
 }

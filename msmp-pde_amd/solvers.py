@@ -106,7 +106,9 @@ class _SolverBase(nn.Module):
 
     def _encode(self, u, pos_x, pos_t, variables, dt):
         if not self.LEM_ENCODER:        # models_gnn.py:269-270
-            return self.embedding_mlp(torch.cat((u, pos_x, variables), -1))
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.embedding_mlp.parameters()):
+                return self.embedding_mlp(torch.cat((u, pos_x, variables), -1))      # differentiable PyTorch path
+            return self._embed_hip(u, pos_x, variables)
         tw = self.time_window
         n = u.shape[0]
         if self.TWO_D:                  # models_gnn2D.py:421-436
@@ -121,6 +123,26 @@ class _SolverBase(nn.Module):
             h = self.embedding_lem(lem_in.permute(1, 0, 2).contiguous())     # differentiable PyTorch restatement
             return self.lemoutput_mlp(h)
         return self.embedding_lem.encode(lem_in, self.lemoutput_mlp)       # fused HIP kernel (recurrence + MLP)
+
+    def _embed_hip(self, u, pos_x, variables):
+        """embedding_mlp as one HIP kernel (msmp_mlp2_swish_f32); the packed weights are cached per parameter version."""
+        lin1, lin2 = self.embedding_mlp[0], self.embedding_mlp[2]
+        ps = (lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        L = lib()
+        k_in = lin1.in_features
+        if getattr(self, '_embed_key', None) != key:
+            f = [p.detach().to(torch.float32).contiguous() for p in ps]
+            blob = torch.empty(L.msmp_packed_mlp2_floats(k_in), dtype=torch.float32, device=u.device)
+            check(L.msmp_pack_mlp2_f32(*[ptr(t) for t in f], k_in, ptr(blob), current_stream()), 'msmp_pack_mlp2_f32')
+            self._embed_blob, self._embed_key = blob, key
+        stride = L.msmp_mlp2_input_stride(k_in)
+        pad = u.new_zeros(u.shape[0], stride - k_in)
+        x = torch.cat((u, pos_x, variables, pad), -1).contiguous()
+        assert x.shape[1] == stride
+        out = torch.empty(u.shape[0], self.hidden_features, dtype=torch.float32, device=u.device)
+        check(L.msmp_mlp2_swish_f32(ptr(x), u.shape[0], k_in, ptr(self._embed_blob), ptr(out), current_stream()), 'msmp_mlp2_swish_f32')
+        return out
 
     # -- forward -------------------------------------------------------------------------------
     def forward(self, data):

@@ -539,3 +539,27 @@ def test_decoder2d_kernel(mp, tw):
     ref = (f(u).reshape(n, 2, tw) + np.cumsum(np.ones(tw) * dt)[None, None, :] * diff).reshape(n, 2 * tw)
     err = np.abs(out.double().cpu().numpy() - ref).max()
     assert err < 1e-6, err
+
+
+@pytest.mark.parametrize('k_in,n', [(28, 777), (29, 128), (59, 1000), (105, 333), (128, 129), (1, 64)])
+def test_embedding_mlp_kernel(mp, k_in, n):
+    """Fused two-layer encoder MLP (embedding_mlp of the LEM-free classes) vs the oracle's linear / swish restatement."""
+    from msmp_pde_amd._lib import check, ptr, current_stream
+    L = mp.lib()
+    rng = np.random.default_rng(500 + k_in)
+    w1 = (rng.uniform(-1, 1, (H, k_in)) / np.sqrt(k_in)).astype(np.float32); b1 = rng.uniform(-.3, .3, H).astype(np.float32)
+    w2 = (rng.uniform(-1, 1, (H, H)) / np.sqrt(H)).astype(np.float32); b2 = rng.uniform(-.3, .3, H).astype(np.float32)
+    x = rng.standard_normal((n, k_in)).astype(np.float32)
+    stride = L.msmp_mlp2_input_stride(k_in)
+    assert stride % 32 == 0 and stride >= k_in and L.msmp_mlp2_input_stride(129) == -1
+    xp = np.zeros((n, stride), np.float32); xp[:, :k_in] = x
+    blob = torch.empty(L.msmp_packed_mlp2_floats(k_in), device='cuda')
+    t = [dev(a) for a in (w1, b1, w2, b2, xp)]
+    st = current_stream()
+    check(L.msmp_pack_mlp2_f32(ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(t[3]), k_in, ptr(blob), st), 'pack mlp2')
+    out = torch.full((n, H), float('nan'), device='cuda')
+    check(L.msmp_mlp2_swish_f32(ptr(t[4]), n, k_in, ptr(blob), ptr(out), st), 'mlp2')
+    f = lambda a: a.astype(np.float64)
+    ref = O.swish(O.linear(O.swish(O.linear(f(x), f(w1), f(b1))), f(w2), f(b2)))
+    err = np.abs(out.double().cpu().numpy() - ref).max()
+    assert err < 1e-6, err
