@@ -237,6 +237,15 @@ int msmp_decoder2d_f32(const float* hd, const float* u, int64_t n_nodes, int tw,
                        const float* b1, const float* w2, const float* b2, float dt, float* out,
                        msmp_stream_t stream);
 
+/* msmp_lem_encoder_f32 with the step inputs assembled in the kernel from the node arrays (no [N, T, ninp] tensor in HBM):
+ *   two_d = 0: x_t = [pos_x, u_t, variables]                                experiments/models_gnn.py:1357-1360, ninp = 2 + nv
+ *   two_d = 1: x_t = [pos_x, u_t, u_{tw+t}, dt_cum_t + pos_t, variables[1:]]  experiments/models_gnn2D.py:429-433, ninp = 3 + nv
+ * u [N, tw] ([N, 2 tw] for two_d), pos_x / pos_t [N], vars [N, nv] (column 0 = pos_t), dt_cum [tw] = cumsum(pde.dt);
+ * `packed` from msmp_pack_lem_f32 with that ninp.  MSMP_ERR_UNSUPPORTED unless the weight-stationary edition is selected. */
+int msmp_lem_encoder_nodes_f32(const float* u, const float* pos_x, const float* pos_t, const float* vars, const float* dt_cum,
+                               int64_t n_nodes, int tw, int nv, int two_d, float dt, const float* packed, int with_mlp,
+                               float* h_out, msmp_stream_t stream);
+
 /* Two-layer node MLP  out = Swish(W2 Swish(W1 x + b1) + b2)  in one launch: the `embedding_mlp` encoder of the LEM-free
  * solver classes (experiments/models_gnn.py:196-201 called at :269-270; models_gnn2D.py:66-71 called at :119-120).
  * w1 [128, k_in] (k_in = in_features of the first Linear <= 128), w2 [128,128], b* [128], reference layout.

@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(PKG, 'libmsmp_pde.so')
 
 MSMP_LAYER_RESIDUAL_SWISH = 0
 MSMP_LAYER_LIN = 1
+MSMP_ERR_UNSUPPORTED = -2
 MSMP_MAX_VARS = 8
 HIDDEN = 128
 
@@ -43,6 +44,7 @@ SIGNATURES = {
     'msmp_decoder_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     'msmp_decoder2d_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     'msmp_node_tail_f32': (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    'msmp_lem_encoder_nodes_f32': (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     'msmp_packed_mlp2_floats': (c_int64, [c_int]),
     'msmp_mlp2_input_stride': (c_int, [c_int]),
     'msmp_pack_mlp2_f32': (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_void_p]),

@@ -700,7 +700,15 @@ __global__ __launch_bounds__(512, 2) void lem_encoder_split2_kernel(LemSplitArgs
 // (exponents clamped at 60 so the product stays finite).
 // ----------------------------------------------------------------------------------------------
 struct LemWsArgs {
-    const float* xin;       // [N, T, 2*NS]
+    const float* xin;       // MODE 0: [N, T, 2*NS] assembled step inputs
+    // MODE 1 / 2: the step inputs are assembled in the kernel from the node arrays (experiments/models_gnn.py:1357-1360:
+    // x_t = [pos_x, u_t, variables]; models_gnn2D.py:429-433: x_t = [pos_x, u_t, u_{tw+t}, cumsum(dt)_t + pos_t, variables[1:]])
+    const float* u;         // [N, tw] (2-D: [N, 2 tw])
+    const float* pos_x;     // [N]
+    const float* pos_t;     // [N]      (2-D only)
+    const float* vars;      // [N, nv]
+    const float* dt_cum;    // [tw]     (2-D only)
+    int tw, nv;
     long n_nodes;
     int t_len, with_mlp;
     float dt;
@@ -715,15 +723,29 @@ struct LemWsArgs {
 
 constexpr int LEM_WS_FR = 1024;      // half8 per (tile) fragment area: [kt 4][s 2][plane 2][lane 64]
 
-template <int P>
-__device__ __forceinline__ void lem_ws_load_x(const float* xin, long node, int t, int t_len, float (&x)[2 * ((P + 1) / 2)]) {
+template <int P, int MODE>
+__device__ __forceinline__ void lem_ws_load_x(const LemWsArgs& a, long node, int t, float (&x)[2 * ((P + 1) / 2)]) {
     constexpr int NS = (P + 1) / 2;
-    const f32x2* p = reinterpret_cast<const f32x2*>(xin + ((size_t)node * t_len + t) * (2 * NS));
+    if (MODE == 0) {
+        const f32x2* p = reinterpret_cast<const f32x2*>(a.xin + ((size_t)node * a.t_len + t) * (2 * NS));
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const f32x2 v = p[i];
-        x[2 * i] = v[0];
-        x[2 * i + 1] = v[1];
+        for (int i = 0; i < NS; ++i) {
+            const f32x2 v = p[i];
+            x[2 * i] = v[0];
+            x[2 * i + 1] = v[1];
+        }
+    } else if (MODE == 1) {             // P = 2 + nv
+        x[0] = a.pos_x[node];
+        x[1] = a.u[(size_t)node * a.tw + t];
+#pragma unroll
+        for (int f = 2; f < 2 * NS; ++f) x[f] = f - 2 < a.nv ? a.vars[(size_t)node * a.nv + (f - 2)] : 0.f;
+    } else {                            // P = 3 + nv
+        x[0] = a.pos_x[node];
+        x[1] = a.u[(size_t)node * 2 * a.tw + t];
+        x[2] = a.u[(size_t)node * 2 * a.tw + a.tw + t];
+        x[3] = a.dt_cum[t] + a.pos_t[node];
+#pragma unroll
+        for (int f = 4; f < 2 * NS; ++f) x[f] = f - 3 < a.nv ? a.vars[(size_t)node * a.nv + (f - 3)] : 0.f;
     }
 }
 
@@ -890,7 +912,7 @@ __device__ __forceinline__ void lem_ws_gemm2(const half8 (&w0)[4][2][2], const h
         }
 }
 
-template <int P>
+template <int P, int MODE>
 __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
     constexpr int NS = (P + 1) / 2, M = (3 * P + 15) / 16;
     // y fragments [buffer 2][tile 2] | z fragments [tile 2] (16 KB each) | scaled biases [512 + 256]
@@ -954,7 +976,7 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
         node[X] = n < a.n_nodes ? n : a.n_nodes - 1;
     }
     float xn[2 * NS];
-    lem_ws_load_x<P>(a.xin, node[0], 0, a.t_len, xn);
+    lem_ws_load_x<P, MODE>(a, node[0], 0, xn);
     __syncthreads();
     if (role) __syncthreads();          // role B runs one stage behind role A
 
@@ -965,7 +987,7 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
             lem_ws_slots<P>(xn, hh, bx);
             {   // prefetch the inputs of this wave's next work item: (tile 1, t) or (tile 0, t + 1)
                 const int tn = X ? (t + 1 < a.t_len ? t + 1 : t) : t;
-                lem_ws_load_x<P>(a.xin, node[X ^ 1], tn, a.t_len, xn);
+                lem_ws_load_x<P, MODE>(a, node[X ^ 1], tn, xn);
             }
             f32x16 acc0, acc1;
             lem_ws_bias(bl0, hh, acc0);
@@ -1083,19 +1105,19 @@ extern "C" int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len
     const unsigned grid = (unsigned)((n_nodes + 127) / 128);
     timing_begin(MSMP_K_LEM, (hipStream_t)stream);
     if (g_lem_split == 3) {
-        LemWsArgs wa{xin, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s, packed + L.mlp_s, packed + L.bias_s,
-                     packed + L.wx_h, packed + L.mlpb_s, packed + L.scales, h_out};
+        LemWsArgs wa{xin, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s,
+                     packed + L.mlp_s, packed + L.bias_s, packed + L.wx_h, packed + L.mlpb_s, packed + L.scales, h_out};
         const unsigned g64 = (unsigned)((n_nodes + 63) / 64);
         hipStream_t st = (hipStream_t)stream;
         switch (ninp) {
-            case 1: hipLaunchKernelGGL(lem_encoder_ws_kernel<1>, dim3(g64), dim3(512), 0, st, wa); break;
-            case 2: hipLaunchKernelGGL(lem_encoder_ws_kernel<2>, dim3(g64), dim3(512), 0, st, wa); break;
-            case 3: hipLaunchKernelGGL(lem_encoder_ws_kernel<3>, dim3(g64), dim3(512), 0, st, wa); break;
-            case 4: hipLaunchKernelGGL(lem_encoder_ws_kernel<4>, dim3(g64), dim3(512), 0, st, wa); break;
-            case 5: hipLaunchKernelGGL(lem_encoder_ws_kernel<5>, dim3(g64), dim3(512), 0, st, wa); break;
-            case 6: hipLaunchKernelGGL(lem_encoder_ws_kernel<6>, dim3(g64), dim3(512), 0, st, wa); break;
-            case 7: hipLaunchKernelGGL(lem_encoder_ws_kernel<7>, dim3(g64), dim3(512), 0, st, wa); break;
-            default: hipLaunchKernelGGL(lem_encoder_ws_kernel<8>, dim3(g64), dim3(512), 0, st, wa); break;
+            case 1: hipLaunchKernelGGL((lem_encoder_ws_kernel<1, 0>), dim3(g64), dim3(512), 0, st, wa); break;
+            case 2: hipLaunchKernelGGL((lem_encoder_ws_kernel<2, 0>), dim3(g64), dim3(512), 0, st, wa); break;
+            case 3: hipLaunchKernelGGL((lem_encoder_ws_kernel<3, 0>), dim3(g64), dim3(512), 0, st, wa); break;
+            case 4: hipLaunchKernelGGL((lem_encoder_ws_kernel<4, 0>), dim3(g64), dim3(512), 0, st, wa); break;
+            case 5: hipLaunchKernelGGL((lem_encoder_ws_kernel<5, 0>), dim3(g64), dim3(512), 0, st, wa); break;
+            case 6: hipLaunchKernelGGL((lem_encoder_ws_kernel<6, 0>), dim3(g64), dim3(512), 0, st, wa); break;
+            case 7: hipLaunchKernelGGL((lem_encoder_ws_kernel<7, 0>), dim3(g64), dim3(512), 0, st, wa); break;
+            default: hipLaunchKernelGGL((lem_encoder_ws_kernel<8, 0>), dim3(g64), dim3(512), 0, st, wa); break;
         }
     } else if (g_lem_split == 1) {
         LemSplitArgs sa{LemArgs{xin, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s, packed + L.mlp_s, packed + L.bias_s,
@@ -1126,4 +1148,40 @@ extern "C" int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len
     }
     timing_end(MSMP_K_LEM, (hipStream_t)stream);
     return check_launch("lem_encoder_kernel");
+}
+
+// The same weight-stationary kernel with the step inputs assembled in the kernel from the node arrays (no [N, T, ninp]
+// tensor in HBM): two_d = 0: x_t = [pos_x, u_t, variables] (experiments/models_gnn.py:1357-1360, ninp = 2 + nv);
+// two_d = 1: x_t = [pos_x, u_t, u_{tw+t}, dt_cum_t + pos_t, variables[1:]] (models_gnn2D.py:429-433, ninp = 3 + nv).
+extern "C" int msmp_lem_encoder_nodes_f32(const float* u, const float* pos_x, const float* pos_t, const float* vars, const float* dt_cum,
+                                          int64_t n_nodes, int tw, int nv, int two_d, float dt, const float* packed, int with_mlp,
+                                          float* h_out, msmp_stream_t stream) {
+    MSMP_REQUIRE(u && pos_x && vars && packed && h_out, MSMP_ERR_ARG, "msmp_lem_encoder_nodes_f32: null pointer");
+    MSMP_REQUIRE(!two_d || (pos_t && dt_cum), MSMP_ERR_ARG, "msmp_lem_encoder_nodes_f32: the 2-D input needs pos_t and dt_cum");
+    MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31) && tw >= 1 && nv >= 1, MSMP_ERR_ARG, "msmp_lem_encoder_nodes_f32: bad sizes");
+    const int ninp = (two_d ? 3 : 2) + nv;
+    MSMP_REQUIRE(ninp <= LEM_MAX_INP, MSMP_ERR_UNSUPPORTED, "msmp_lem_encoder_nodes_f32: ninp=%d > %d", ninp, LEM_MAX_INP);
+    MSMP_REQUIRE(g_lem_split == 3, MSMP_ERR_UNSUPPORTED, "msmp_lem_encoder_nodes_f32: only the weight-stationary edition (msmp_tune lem 3)");
+    const LemLayout L = lem_layout();
+    LemWsArgs wa{nullptr, u, pos_x, pos_t, vars, dt_cum, tw, nv, (long)n_nodes, tw, with_mlp, dt, packed + L.rec_s, packed + L.mlp_s,
+                 packed + L.bias_s, packed + L.wx_h, packed + L.mlpb_s, packed + L.scales, h_out};
+    const unsigned g64 = (unsigned)((n_nodes + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+    timing_begin(MSMP_K_LEM, st);
+    if (!two_d) switch (ninp) {
+        case 3: hipLaunchKernelGGL((lem_encoder_ws_kernel<3, 1>), dim3(g64), dim3(512), 0, st, wa); break;
+        case 4: hipLaunchKernelGGL((lem_encoder_ws_kernel<4, 1>), dim3(g64), dim3(512), 0, st, wa); break;
+        case 5: hipLaunchKernelGGL((lem_encoder_ws_kernel<5, 1>), dim3(g64), dim3(512), 0, st, wa); break;
+        case 6: hipLaunchKernelGGL((lem_encoder_ws_kernel<6, 1>), dim3(g64), dim3(512), 0, st, wa); break;
+        case 7: hipLaunchKernelGGL((lem_encoder_ws_kernel<7, 1>), dim3(g64), dim3(512), 0, st, wa); break;
+        default: hipLaunchKernelGGL((lem_encoder_ws_kernel<8, 1>), dim3(g64), dim3(512), 0, st, wa); break;
+    } else switch (ninp) {
+        case 4: hipLaunchKernelGGL((lem_encoder_ws_kernel<4, 2>), dim3(g64), dim3(512), 0, st, wa); break;
+        case 5: hipLaunchKernelGGL((lem_encoder_ws_kernel<5, 2>), dim3(g64), dim3(512), 0, st, wa); break;
+        case 6: hipLaunchKernelGGL((lem_encoder_ws_kernel<6, 2>), dim3(g64), dim3(512), 0, st, wa); break;
+        case 7: hipLaunchKernelGGL((lem_encoder_ws_kernel<7, 2>), dim3(g64), dim3(512), 0, st, wa); break;
+        default: hipLaunchKernelGGL((lem_encoder_ws_kernel<8, 2>), dim3(g64), dim3(512), 0, st, wa); break;
+    }
+    timing_end(MSMP_K_LEM, st);
+    return check_launch("lem_encoder_ws_kernel");
 }

@@ -14,7 +14,7 @@ import math
 import torch
 from torch import nn
 
-from ._lib import lib, check, ptr, current_stream
+from ._lib import lib, check, ptr, current_stream, MSMP_ERR_UNSUPPORTED
 
 
 class LEMcuda(nn.Module):
@@ -84,6 +84,22 @@ class LEM(nn.Module):
             check(L.msmp_pack_lem_f32(*args, self.ninp, ptr(blob), current_stream()), 'msmp_pack_lem_f32')
             self._packed, self._packed_key = blob, key
         return self._packed
+
+    def encode_nodes(self, u, pos_x, pos_t, variables, dt_cum, two_d, mlp=None):
+        """Same as `encode` with the step inputs assembled inside the kernel from the node arrays (models_gnn.py:1357-1360 /
+        models_gnn2D.py:429-433).  Returns None when the selected kernel edition has no such entry (msmp_tune "lem" != 3)."""
+        L = lib()
+        n, nv = u.shape[0], variables.shape[1]
+        tw = u.shape[1] // (2 if two_d else 1)
+        assert self.nhid == 128 and self.ninp == (3 if two_d else 2) + nv
+        t = [x.to(torch.float32).contiguous() for x in (u, pos_x, pos_t, variables, dt_cum)]
+        out = torch.empty(n, self.nhid, dtype=torch.float32, device=u.device)
+        rc = L.msmp_lem_encoder_nodes_f32(ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(t[3]), ptr(t[4]), n, tw, nv, int(two_d), self.rnn.dt,
+                                          ptr(self._pack(mlp)), int(mlp is not None), ptr(out), current_stream())
+        if rc == MSMP_ERR_UNSUPPORTED:
+            return None
+        check(rc, 'msmp_lem_encoder_nodes_f32')
+        return out
 
     def encode(self, xin, mlp=None):
         """xin [N, T, ninp] float32 CUDA (node-major step inputs) -> [N, nhid]; `mlp` = lemoutput_mlp

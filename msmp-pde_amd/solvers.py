@@ -111,6 +111,11 @@ class _SolverBase(nn.Module):
             return self._embed_hip(u, pos_x, variables)
         tw = self.time_window
         n = u.shape[0]
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.embedding_lem.parameters())
+        if not grad:                    # step inputs assembled inside the kernel (no [N, T, ninp] tensor)
+            h = self.embedding_lem.encode_nodes(u, pos_x, pos_t, variables, dt, self.TWO_D, self.lemoutput_mlp)
+            if h is not None:
+                return h
         if self.TWO_D:                  # models_gnn2D.py:421-436
             ts = dt.view(1, tw) + pos_t
             lem_in = torch.stack([pos_x.expand(n, tw), u[:, :tw], u[:, tw:], ts], -1)       # [N, tw, 4]
@@ -119,7 +124,7 @@ class _SolverBase(nn.Module):
             t_len = u.shape[1]
             lem_in = torch.cat((pos_x[:, None, :].expand(n, t_len, 1), u[:, :, None],
                                 variables[:, None, :].expand(n, t_len, variables.shape[1])), -1)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.embedding_lem.parameters()):
+        if grad:
             h = self.embedding_lem(lem_in.permute(1, 0, 2).contiguous())     # differentiable PyTorch restatement
             return self.lemoutput_mlp(h)
         return self.embedding_lem.encode(lem_in, self.lemoutput_mlp)       # fused HIP kernel (recurrence + MLP)

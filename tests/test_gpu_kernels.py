@@ -563,3 +563,32 @@ def test_embedding_mlp_kernel(mp, k_in, n):
     ref = O.swish(O.linear(O.swish(O.linear(f(x), f(w1), f(b1))), f(w2), f(b2)))
     err = np.abs(out.double().cpu().numpy() - ref).max()
     assert err < 1e-6, err
+
+
+@pytest.mark.parametrize('two_d,nv,tw,n', [(False, 2, 25, 300), (False, 6, 20, 65), (True, 3, 25, 129), (True, 5, 50, 64)])
+def test_lem_encoder_in_kernel_input_assembly(mp, two_d, nv, tw, n):
+    """msmp_lem_encoder_nodes_f32 (step inputs assembled in the kernel, models_gnn.py:1357-1360 / models_gnn2D.py:429-433)
+    is bit-identical to the same kernel fed with the assembled [N, T, ninp] tensor."""
+    torch.manual_seed(nv)
+    ninp = (3 if two_d else 2) + nv
+    lem = mp.LEM(ninp, 128).cuda()
+    mlp = torch.nn.Sequential(torch.nn.Linear(128, 128), mp.Swish(), torch.nn.Linear(128, 128), mp.Swish()).cuda()
+    u = torch.randn(n, 2 * tw if two_d else tw, device='cuda')
+    pos_x, pos_t = torch.rand(n, 1, device='cuda'), torch.rand(n, 1, device='cuda')
+    variables = torch.cat((pos_t, torch.rand(n, nv - 1, device='cuda')), -1)
+    dt = torch.cumsum(torch.ones(tw, device='cuda') * 0.016, 0)
+    if two_d:
+        ts = dt.view(1, tw) + pos_t
+        xin = torch.stack([pos_x.expand(n, tw), u[:, :tw], u[:, tw:], ts], -1)
+        xin = torch.cat((xin, variables[:, None, 1:].expand(n, tw, nv - 1)), -1)
+    else:
+        xin = torch.cat((pos_x[:, None, :].expand(n, tw, 1), u[:, :, None], variables[:, None, :].expand(n, tw, nv)), -1)
+    with torch.no_grad():
+        ref = lem.encode(xin.contiguous(), mlp)
+        out = lem.encode_nodes(u, pos_x, pos_t, variables, dt, two_d, mlp)
+        assert out is not None and torch.equal(out, ref)
+        mp.lib().msmp_tune(b'lem', 1)
+        try:
+            assert lem.encode_nodes(u, pos_x, pos_t, variables, dt, two_d, mlp) is None      # only the default edition has it
+        finally:
+            mp.lib().msmp_tune(b'lem', 3)
