@@ -723,8 +723,11 @@ struct LemWsArgs {
 
 constexpr int LEM_WS_FR = 1024;      // half8 per (tile) fragment area: [kt 4][s 2][plane 2][lane 64]
 
+// Step inputs of one node.  MODE 0: from the assembled tensor.  MODE 1 / 2: the per-node constants (pos_x, variables; pos_t)
+// come from a 2-KB LDS table filled in the prologue (kept out of registers: hoisted into the time loop's live range they
+// spilled), the time-dependent entries (u_t; u_{tw+t}, dt_cum_t + pos_t) are loaded per step.
 template <int P, int MODE>
-__device__ __forceinline__ void lem_ws_load_x(const LemWsArgs& a, long node, int t, float (&x)[2 * ((P + 1) / 2)]) {
+__device__ __forceinline__ void lem_ws_load_x(const LemWsArgs& a, const float* xc, long node, int t, float (&x)[2 * ((P + 1) / 2)]) {
     constexpr int NS = (P + 1) / 2;
     if (MODE == 0) {
         const f32x2* p = reinterpret_cast<const f32x2*>(a.xin + ((size_t)node * a.t_len + t) * (2 * NS));
@@ -734,18 +737,20 @@ __device__ __forceinline__ void lem_ws_load_x(const LemWsArgs& a, long node, int
             x[2 * i] = v[0];
             x[2 * i + 1] = v[1];
         }
-    } else if (MODE == 1) {             // P = 2 + nv
-        x[0] = a.pos_x[node];
-        x[1] = a.u[(size_t)node * a.tw + t];
+    } else {
 #pragma unroll
-        for (int f = 2; f < 2 * NS; ++f) x[f] = f - 2 < a.nv ? a.vars[(size_t)node * a.nv + (f - 2)] : 0.f;
-    } else {                            // P = 3 + nv
-        x[0] = a.pos_x[node];
-        x[1] = a.u[(size_t)node * 2 * a.tw + t];
-        x[2] = a.u[(size_t)node * 2 * a.tw + a.tw + t];
-        x[3] = a.dt_cum[t] + a.pos_t[node];
-#pragma unroll
-        for (int f = 4; f < 2 * NS; ++f) x[f] = f - 3 < a.nv ? a.vars[(size_t)node * a.nv + (f - 3)] : 0.f;
+        for (int i = 0; i < NS; ++i) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(xc + 2 * i);
+            x[2 * i] = v[0];
+            x[2 * i + 1] = v[1];
+        }
+        if (MODE == 1) {
+            x[1] = a.u[(size_t)node * a.tw + t];
+        } else {
+            x[1] = a.u[(size_t)node * 2 * a.tw + t];
+            x[2] = a.u[(size_t)node * 2 * a.tw + a.tw + t];
+            x[3] = a.dt_cum[t] + x[3];
+        }
     }
 }
 
@@ -917,6 +922,7 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
     constexpr int NS = (P + 1) / 2, M = (3 * P + 15) / 16;
     // y fragments [buffer 2][tile 2] | z fragments [tile 2] (16 KB each) | scaled biases [512 + 256]
     __shared__ __attribute__((aligned(16))) float lds[6 * SPLIT_CHUNK_FLOATS + 768];
+    __shared__ __attribute__((aligned(16))) float xconst[64 * 8];
     half8* const yfr = reinterpret_cast<half8*>(lds);
     half8* const zfr = yfr + 4 * LEM_WS_FR;
     float* const bias_l = lds + 6 * SPLIT_CHUNK_FLOATS;
@@ -936,6 +942,19 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
         for (int i = 0; i < 4; ++i) yfr[tid + 512 * i] = zero;
         bias_l[tid] = a.bias_s[tid];
         if (tid < 256) bias_l[512 + tid] = a.mlpb_s[tid];
+        if (MODE != 0 && tid < 64) {        // per-node constants of the 64 nodes: [pos_x, (u_t), variables] / [pos_x, (u_t, u_tw+t), pos_t, variables[1:]]
+            const long nn = n0 + tid < a.n_nodes ? n0 + tid : a.n_nodes - 1;
+            float* row = xconst + 8 * tid;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) row[f] = 0.f;
+            row[0] = a.pos_x[nn];
+            if (MODE == 1) {
+                for (int f = 0; f < a.nv; ++f) row[2 + f] = a.vars[(size_t)nn * a.nv + f];
+            } else {
+                row[3] = a.pos_t[nn];
+                for (int f = 1; f < a.nv; ++f) row[3 + f] = a.vars[(size_t)nn * a.nv + f];
+            }
+        }
     }
     half8 w[2][4][2][2];
     half8 wxh[2][M];
@@ -976,7 +995,8 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
         node[X] = n < a.n_nodes ? n : a.n_nodes - 1;
     }
     float xn[2 * NS];
-    lem_ws_load_x<P, MODE>(a, node[0], 0, xn);
+    __syncthreads();                    // the constants table is read below
+    lem_ws_load_x<P, MODE>(a, xconst + 8 * c, node[0], 0, xn);
     __syncthreads();
     if (role) __syncthreads();          // role B runs one stage behind role A
 
@@ -987,7 +1007,7 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
             lem_ws_slots<P>(xn, hh, bx);
             {   // prefetch the inputs of this wave's next work item: (tile 1, t) or (tile 0, t + 1)
                 const int tn = X ? (t + 1 < a.t_len ? t + 1 : t) : t;
-                lem_ws_load_x<P, MODE>(a, node[X ^ 1], tn, xn);
+                lem_ws_load_x<P, MODE>(a, xconst + 8 * (32 * (X ^ 1) + c), node[X ^ 1], tn, xn);
             }
             f32x16 acc0, acc1;
             lem_ws_bias(bl0, hh, acc0);
@@ -1074,6 +1094,7 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
 
 using namespace msmp;
 
+int g_lem_nodes = 1;     // msmp_tune("lem_nodes", 0): msmp_lem_encoder_nodes_f32 declines, callers assemble the [N,T,ninp] tensor (A/B)
 int g_lem_split = 3;     // 3: weight-stationary split kernel, 1: streamed-weight two-waves-per-SIMD split kernel, 2: one-wave split kernel,
                          // 0: fp32 MFMA (msmp_tune "lem"; "split" 1/0 selects 3/0)
 extern "C" int64_t msmp_packed_lem_floats(void) { return lem_layout().total; }
@@ -1161,7 +1182,7 @@ extern "C" int msmp_lem_encoder_nodes_f32(const float* u, const float* pos_x, co
     MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31) && tw >= 1 && nv >= 1, MSMP_ERR_ARG, "msmp_lem_encoder_nodes_f32: bad sizes");
     const int ninp = (two_d ? 3 : 2) + nv;
     MSMP_REQUIRE(ninp <= LEM_MAX_INP, MSMP_ERR_UNSUPPORTED, "msmp_lem_encoder_nodes_f32: ninp=%d > %d", ninp, LEM_MAX_INP);
-    MSMP_REQUIRE(g_lem_split == 3, MSMP_ERR_UNSUPPORTED, "msmp_lem_encoder_nodes_f32: only the weight-stationary edition (msmp_tune lem 3)");
+    MSMP_REQUIRE(g_lem_split == 3 && g_lem_nodes, MSMP_ERR_UNSUPPORTED, "msmp_lem_encoder_nodes_f32: only the weight-stationary edition (msmp_tune lem 3)");
     const LemLayout L = lem_layout();
     LemWsArgs wa{nullptr, u, pos_x, pos_t, vars, dt_cum, tw, nv, (long)n_nodes, tw, with_mlp, dt, packed + L.rec_s, packed + L.mlp_s,
                  packed + L.bias_s, packed + L.wx_h, packed + L.mlpb_s, packed + L.scales, h_out};

@@ -1197,6 +1197,7 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
 using namespace msmp;
 
 extern int g_lem_split;
+extern int g_lem_nodes;
 static int g_split = 1;      // fp16-split matrix path (default); msmp_tune("split", 0) selects the fp32-MFMA kernels
 
 extern "C" int msmp_edge_mlp_f32(const float* h, const float* u, const float* pos, const float* vars,
@@ -1256,6 +1257,7 @@ extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_occ")) { g_edge_occ = value; return MSMP_OK; }
     if (key && !strcmp(key, "lem")) { g_lem_split = value; return MSMP_OK; }
+    if (key && !strcmp(key, "lem_nodes")) { g_lem_nodes = value; return MSMP_OK; }
     if (key && !strcmp(key, "split")) { g_split = value; g_lem_split = value ? 3 : 0; return MSMP_OK; }
     msmp::set_error("msmp_tune: unknown key");
     return MSMP_ERR_ARG;
