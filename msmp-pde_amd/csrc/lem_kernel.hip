@@ -798,33 +798,6 @@ __device__ __forceinline__ void lem_ws_publish(const f32x16& st, half8* area, in
     }
 }
 
-// packed fp32 arithmetic (two values per instruction at the single-value issue cost); the compiler scalarises most
-// <2 x float> expressions, so the activation pipeline names the instructions
-__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
-    f32x2 d;
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {           // a - b
-    f32x2 d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) {  // c - a b
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
 __device__ __forceinline__ float vmin(float a, float b) {            // bare v_min_f32 (fminf adds a canonicalising v_max)
     float d;
     asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));

@@ -100,6 +100,33 @@ __device__ __forceinline__ void acc_init_bias(const float* __restrict__ bias, in
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int SPLIT_CHUNK_FLOATS = 4096;      // 16 KB, same footprint as an fp32 chunk
 
+// packed fp32 arithmetic (two values per instruction at the single-value issue cost); the compiler scalarises most
+// <2 x float> expressions, so the activation pipeline names the instructions
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {           // a - b
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) {  // c - a b
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 using half2 = __attribute__((ext_vector_type(2))) _Float16;
 // lo = fp16(x - float(hi)) for a pair: one mixed-precision FMA per value (x - hi is exact in fp32, so this equals the
 // convert-back / subtract / convert sequence bit for bit, in 2 instructions instead of 5).  Inline asm is invisible to the
