@@ -46,6 +46,17 @@ def test_argument_errors_are_reported_not_thrown(mp):
     assert rc == -1 and b'null pointer' in L.msmp_last_error()
     rc = L.msmp_mp_layer_f32(*([None] * 8), 1, 1, 1, 6, 100, 25, 2, None, None, 0, 1e-5, None, None, 0, None)
     assert rc == -1
+    # every new entry point of this round validates its arguments the same way (no device work happens on these calls)
+    assert L.msmp_node_tail_f32(*([None] * 5), 10, 1, 100, 2, None, None, 1, 1e-5, None, None) == -1
+    assert L.msmp_mlp2_swish_f32(None, 10, 28, None, None, None) == -1
+    assert L.msmp_lem_encoder_nodes_f32(*([None] * 5), 10, 25, 2, 0, 1.0, None, 1, None, None) == -1
+    assert L.msmp_decoder2d_f32(None, None, 10, 25, None, None, None, None, 0.016, None, None) == -1
+    assert L.msmp_packed_mlp2_floats(28) == 32 + 256 + (1 + 4) * 4096 and L.msmp_packed_mlp2_floats(129) == -1
+    assert L.msmp_mlp2_input_stride(28) == 32 and L.msmp_mlp2_input_stride(59) == 64
+    # knobs: known keys are accepted, unknown ones rejected with a message
+    for key in (b'split', b'edge_nb', b'edge_occ', b'edge_ws', b'tail', b'lem', b'lem_nodes'):
+        assert L.msmp_tune(key, {b'split': 1, b'edge_occ': 4, b'tail': 1, b'lem': 3, b'lem_nodes': 1}.get(key, 0)) == 0, key
+    assert L.msmp_tune(b'no_such_knob', 1) != 0 and b'unknown key' in L.msmp_last_error()
 
 
 @pytest.mark.parametrize('exp', ['E2', 'WE3', 'RPU', 'MSWG3'])
