@@ -33,6 +33,7 @@ struct EdgeArgs {
     const int* rowptr;   // FUSE only
     long n_edges, n_nodes;
     int tile_nodes;      // FUSE only: nodes per workgroup tile (tile_nodes * max in-degree <= 128*NB)
+    int xcd_map;         // FUSE only: workgroup b works on tile (b % 8) * ceil(tiles / 8) + b / 8 (consecutive tiles on one XCD)
     int tw, nv, nc1;
     const float* w1;   // nc1 chunks
     const float* w2;   // 4 chunks
@@ -124,7 +125,15 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
     long tile_e0, tile_e1;     // CSR edge range of this workgroup
     int tile_n0 = 0, tile_n1 = 0;
     if (FUSE) {
-        tile_n0 = blockIdx.x * a.tile_nodes;
+        // Workgroups are dealt round-robin over the 8 XCDs; with xcd_map each XCD gets a contiguous run of tiles, so the
+        // source rows that neighbouring tiles share (28 % of a tile's Q rows on the 1-D grids) meet in that XCD's L2.
+        unsigned tile = blockIdx.x;
+        if (a.xcd_map) {
+            const unsigned per = (gridDim.x + 7) / 8;
+            tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+            if ((long)tile * a.tile_nodes >= a.n_nodes) return;     // padding slots of the 8 x ceil(tiles / 8) enumeration
+        }
+        tile_n0 = tile * a.tile_nodes;
         tile_n1 = min((long)tile_n0 + a.tile_nodes, a.n_nodes);
         tile_e0 = a.rowptr[tile_n0];
         tile_e1 = a.rowptr[tile_n1];
@@ -1209,7 +1218,7 @@ extern "C" int msmp_edge_mlp_f32(const float* h, const float* u, const float* po
     MSMP_REQUIRE(n_edges < (1L << 31) && n_nodes < (1L << 31), MSMP_ERR_UNSUPPORTED, "msmp_edge_mlp_f32: int32 index range");
     if (n_edges == 0) return MSMP_OK;
     const PackedLayout L = packed_layout(tw, nv);
-    EdgeArgs a{h, u, pos, vars, tgt, col, nullptr, (long)n_edges, (long)n_nodes, 0, tw, nv, L.nc1,
+    EdgeArgs a{h, u, pos, vars, tgt, col, nullptr, (long)n_edges, (long)n_nodes, 0, 0, tw, nv, L.nc1,
                packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, nullptr, nullptr, msg_out, nullptr};
     constexpr int NB = 2;
     const unsigned grid = (unsigned)((n_edges + 128 * NB - 1) / (128 * NB));
@@ -1241,6 +1250,7 @@ static int g_edge_occ = 4;     // 4 waves per SIMD (128 registers) measured 5 % 
 static int g_edge_nb = 0;    // tuning override (msmp_tune): 0 = automatic, 1 / 2 = force the tile size of the factorised kernel
 
 extern int g_edge_ws_waves;
+static int g_edge_xcd = 0;   // XCD-contiguous tile order in the fused message kernels (msmp_tune "edge_xcd")
 static int g_edge_ws = 0;    // 1: persistent weight-stationary message + mean kernel (max in-degree <= 32; msmp_tune "edge_ws");
                              // measured equal to the streamed-weight kernel (2.43 vs 2.41 ms per step), so the latter stays the default
 static int g_tail = 1;       // fused node tail (msmp_node_tail_f32) inside msmp_mp_layer_f32; msmp_tune("tail", 0) chains the pieces
@@ -1253,6 +1263,7 @@ int msmp_tune_get(const char* key) {
 extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "tail")) { g_tail = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_ws")) { g_edge_ws = value; return MSMP_OK; }
+    if (key && !strcmp(key, "edge_xcd")) { g_edge_xcd = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_ws_waves")) { g_edge_ws_waves = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_occ")) { g_edge_occ = value; return MSMP_OK; }
@@ -1286,9 +1297,10 @@ static int edge_aggregate(const float* h, const float* u, const float* pos, cons
     const PackedLayout L = packed_layout(tw, nv);
     int tile_nodes = max_in_degree > 0 ? edges_per_tile / max_in_degree : edges_per_tile;
     if (tile_nodes > 256) tile_nodes = 256;      // keeps the per-tile node loop short when degrees are tiny
-    EdgeArgs a{h, u, pos, vars, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, tw, nv, L.nc1,
+    EdgeArgs a{h, u, pos, vars, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, g_edge_xcd, tw, nv, L.nc1,
                packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, P, Q, nullptr, agg_out};
-    const unsigned grid = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
+    unsigned grid = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
+    if (g_edge_xcd) grid = (grid + 7) / 8 * 8;      // the XCD remap enumerates 8 x ceil(tiles / 8) slots; slots past the last tile exit
     timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
     if (P && g_split && g_edge_ws && max_in_degree >= 1 && max_in_degree <= 32)
         msmp_launch_edge_ws(P, Q, rowptr, col, tgt, n_nodes, max_in_degree, packed + L.w2t, packed + L.b2, packed + L.scales, agg_out,

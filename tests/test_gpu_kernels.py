@@ -201,6 +201,14 @@ def test_layer_pieces_vs_oracle(mp, tw, nv, sizes, shuffle):
     check(L.msmp_edge_aggregate_f32(ptr(dh), ptr(du), ptr(dpos), ptr(dvar), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt), n, e,
                                     gs.max_in_degree, tw, nv, ptr(blob), ptr(agg_f), st), 'edge_aggregate')
     assert torch.equal(agg_f, agg)
+    L.msmp_tune(b'edge_xcd', 1)       # XCD-contiguous tile order: another enumeration of the same tiles
+    try:
+        agg_x = torch.full((n, H), float('nan'), device='cuda')
+        check(L.msmp_edge_aggregate_f32(ptr(dh), ptr(du), ptr(dpos), ptr(dvar), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt), n, e,
+                                        gs.max_in_degree, tw, nv, ptr(blob), ptr(agg_x), st), 'edge_aggregate xcd')
+    finally:
+        L.msmp_tune(b'edge_xcd', 0)
+    assert torch.equal(agg_x, agg)
 
     # factorised message_net_1: P[i] + Q[j] from per-node projections, same result up to rounding
     P, Q = torch.empty(n, H, device='cuda'), torch.empty(n, H, device='cuda')
