@@ -25,7 +25,9 @@ constexpr int LEM_MAX_INP = 8;
 constexpr int LEM_WXH_FLOATS = 4 * 4 * 2 * 64 * 8 / 2;
 
 // Slot s (0..31) of the K axis of the input MFMAs pairs  A: w_hi[f] | w_hi[f] | w_lo[f]   with   B: x_hi[f] | x_lo[f] | x_hi[f]
-// for s in [0,P) | [P,2P) | [2P,3P)  (zero beyond), so one K=16 MFMA (P <= 5) or two (P <= 8) add W[:, H:] x in fp32-class accuracy.
+// for s in [0,P) | [P,2P) | [2P,3P), then  A: bias_hi | bias_lo  with  B: 1 | 1  at s = 3P, 3P + 1 (zero beyond): one K=16 MFMA
+// (P <= 4) or two (P <= 8) produce  bias + W[:, H:] x  in fp32-class accuracy from a ZERO accumulator input, so the gate
+// accumulators need no initialisation at all.
 __host__ __device__ inline int lem_slot_feature(int slot, int P) { return slot < 3 * P ? slot % P : -1; }
 __host__ __device__ inline int lem_slot_part(int slot, int P) { return slot / P; }   // 0: (hi,hi) 1: (hi,lo) 2: (lo,hi)
 
@@ -157,6 +159,11 @@ __global__ void pack_lem_split_kernel(LemPackArgs a) {
         const int j = (int)(p & 7), lane = (int)(p >> 3) & 63, m = (int)(p >> 9) & 1, T = (int)(p >> 10) & 3, grp = (int)(p >> 12);
         const int slot = 16 * m + 8 * (lane >> 5) + j, f = lem_slot_feature(slot, a.ninp), row = 32 * T + (lane & 31);
         _Float16 v = (_Float16)0.f;
+        if (slot == 3 * a.ninp || slot == 3 * a.ninp + 1) {       // bias slots (paired with 1.0): g2, g3, g1 of `b`, then bz
+            const float bv = (grp == 0 ? a.b[H + row] : grp == 1 ? a.b[2 * H + row] : grp == 2 ? a.b[row] : a.bz[row]) * sc[grp < 3 ? 0 : 1];
+            const _Float16 hi = (_Float16)bv;
+            v = slot == 3 * a.ninp ? hi : (_Float16)(bv - (float)hi);
+        }
         if (f >= 0) {
             // groups in consumption order g2, g3, g1 (rows H.., 2H.., 0.. of W), lin (Wz)
             const float w = (grp == 0 ? a.w[(size_t)(H + row) * kin + H + f] : grp == 1 ? a.w[(size_t)(2 * H + row) * kin + H + f]
@@ -756,8 +763,8 @@ __device__ __forceinline__ void lem_ws_load_x(const LemWsArgs& a, const float* x
 
 // B fragments of the input MFMAs from one node's step inputs
 template <int P>
-__device__ __forceinline__ void lem_ws_slots(const float (&x)[2 * ((P + 1) / 2)], int hh, half8 (&bx)[(3 * P + 15) / 16]) {
-    constexpr int M = (3 * P + 15) / 16;
+__device__ __forceinline__ void lem_ws_slots(const float (&x)[2 * ((P + 1) / 2)], int hh, half8 (&bx)[(3 * P + 2 + 15) / 16]) {
+    constexpr int M = (3 * P + 2 + 15) / 16;
     _Float16 xh[P], xl[P];
 #pragma unroll
     for (int f = 0; f < P; ++f) {
@@ -769,8 +776,8 @@ __device__ __forceinline__ void lem_ws_slots(const float (&x)[2 * ((P + 1) / 2)]
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int s0 = 16 * m + j, s1 = 16 * m + 8 + j;
-            const _Float16 v0 = s0 < 3 * P ? (s0 / P == 1 ? xl[s0 % P] : xh[s0 % P]) : (_Float16)0.f;
-            const _Float16 v1 = s1 < 3 * P ? (s1 / P == 1 ? xl[s1 % P] : xh[s1 % P]) : (_Float16)0.f;
+            const _Float16 v0 = s0 < 3 * P ? (s0 / P == 1 ? xl[s0 % P] : xh[s0 % P]) : (_Float16)(s0 < 3 * P + 2 ? 1.f : 0.f);
+            const _Float16 v1 = s1 < 3 * P ? (s1 / P == 1 ? xl[s1 % P] : xh[s1 % P]) : (_Float16)(s1 < 3 * P + 2 ? 1.f : 0.f);
             bx[m][j] = hh ? v1 : v0;
         }
 }
@@ -892,7 +899,7 @@ __device__ __forceinline__ void lem_ws_gemm2(const half8 (&w0)[4][2][2], const h
 
 template <int P, int MODE>
 __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
-    constexpr int NS = (P + 1) / 2, M = (3 * P + 15) / 16;
+    constexpr int NS = (P + 1) / 2, M = (3 * P + 2 + 15) / 16;
     // y fragments [buffer 2][tile 2] | z fragments [tile 2] (16 KB each) | scaled biases [512 + 256]
     __shared__ __attribute__((aligned(16))) float lds[6 * SPLIT_CHUNK_FLOATS + 768];
     __shared__ __attribute__((aligned(16))) float xconst[64 * 8];
@@ -948,9 +955,6 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
             for (int m = 0; m < M; ++m) wxh[gi][m] = wh[((grp * 4 + ks) * 2 + m) * 64 + lane];
         }
     }
-    // bias rows of the two gates (bias_s order: g1, g2, g3, bz):  role A: g2, g3;  role B: g1, bz
-    const float* bl0 = bias_l + (role ? 0 : H) + 32 * ks;
-    const float* bl1 = bias_l + (role ? 3 * H : 2 * H) + 32 * ks;
     // exponent constants: gate 0 is the sigmoid gate (W scale); gate 1 the tanh candidate (role A: W, role B: Wz)
     const float c0 = -inv_w * LOG2E, c1 = -2.0f * (role ? inv_z : inv_w) * LOG2E, idt = 1.0f / a.dt;
     const LemActConst kc{f32x2{c0, c0}, f32x2{c1, c1}, f32x2{idt, idt}, f32x2{1.0f, 1.0f}};
@@ -982,11 +986,12 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
                 const int tn = X ? (t + 1 < a.t_len ? t + 1 : t) : t;
                 lem_ws_load_x<P, MODE>(a, xconst + 8 * (32 * (X ^ 1) + c), node[X ^ 1], tn, xn);
             }
-            f32x16 acc0, acc1;
-            lem_ws_bias(bl0, hh, acc0);
-            lem_ws_bias(bl1, hh, acc1);
+            // bias + input columns from a zero accumulator input (the bias rides in two K slots paired with 1.0)
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxh[0][0], bx[0], zero, 0, 0, 0);
+            f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxh[1][0], bx[0], zero, 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < M; ++m) {
+            for (int m = 1; m < M; ++m) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxh[0][m], bx[m], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxh[1][m], bx[m], acc1, 0, 0, 0);
             }
