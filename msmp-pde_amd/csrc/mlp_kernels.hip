@@ -694,6 +694,14 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs s
 #pragma unroll
             for (int r = 0; r < 16; ++r) { p[T][r] = bv[T]; qa[T][r] = 0.f; }
     }
+    // step st = 0..7 uses weight chunk (st & 1 ? 4 : 0) + (st >> 1) (P then Q of the same h chunk st >> 1)
+    // Issue order = order of first use (the memory counter retires in order): weight chunk 0 and the first h chunk, THEN the
+    // tail features, which are consumed after the eight main steps -- issued first, they made the first LDS store wait for 33
+    // scattered 4-byte loads (30 % of the kernel).
+    WStage ws;
+    BStage bs;
+    wstage_load(ws, sa.w1s, tid);
+    bstage_load(bs, a.h, n0, a.n_nodes, 0, tid);
     // tail features of this lane's node, k = 16 s + 8 hh + j: [u (tw), pos, vars (nv), 0...]; loads first, selection later
     float tu[16], tv[16];
     const float* un = a.u + (size_t)nc * a.tw;
@@ -704,11 +712,6 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs s
         tu[i] = un[min(k, a.tw - 1)];
         tv[i] = a.vars[(size_t)nc * a.nv + min(max(k - a.tw - 1, 0), a.nv - 1)];
     }
-    // step st = 0..7 uses weight chunk (st & 1 ? 4 : 0) + (st >> 1) (P then Q of the same h chunk st >> 1)
-    WStage ws;
-    BStage bs;
-    wstage_load(ws, sa.w1s, tid);
-    bstage_load(bs, a.h, n0, a.n_nodes, 0, tid);
     wstage_store_linear(ws, wbuf, tid);
     bstage_store(bs, bbuf, tid);
     __syncthreads();

@@ -1,0 +1,21 @@
+"""Wall time of one training iteration (train.training_step: pushforward unroll under no_grad + forward/backward + AdamW)
+on the HIP forward / PyTorch-recompute backward path, E2, reference batch size 16 and larger."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import msmp_pde_amd as mp
+from msmp_pde_amd.synthetic import make_case, EXPERIMENTS
+from msmp_pde_amd.train import training_step
+for name in ('MSMP-PDE', 'Gated', 'MP-PDE'):
+    for bsz in (16, 128):
+        torch.manual_seed(0)
+        case = make_case('E2', bsz, seed=1, device='cuda', dtype=torch.float32)
+        model = mp.MODEL_NAMES[name](case.pde, time_window=25, eq_variables=EXPERIMENTS['E2'], hidden_layer=6).cuda().train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-8, fused=True)
+        steps = [60] * bsz
+        for _ in range(2): training_step(model, case.creator, case.u_super, case.x, case.variables, steps, 1, opt)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        n = 5
+        for _ in range(n): loss = training_step(model, case.creator, case.u_super, case.x, case.variables, steps, 1, opt)
+        torch.cuda.synchronize()
+        print(f'{name:9s} batch {bsz:4d}: {(time.perf_counter() - t0) / n * 1e3:8.2f} ms per training iteration (1 unrolled step), loss {float(loss):.4f}', flush=True)
