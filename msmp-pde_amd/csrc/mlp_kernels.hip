@@ -306,13 +306,15 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
         constexpr int CPR = 32 * TPR, LDR = CPR + 4;      // channels per round, LDS row stride (dwords; 4*odd)
         constexpr int NCQ = CPR / 4, NSLOT = 256 / NCQ;
         const int cq = tid & (NCQ - 1), slot = tid / NCQ;
+        // unconditional loads from clamped indices, selected afterwards (predicated loads compile into separately waited-for blocks)
         int r0a[4], r1a[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int node = tile_n0 + slot + k * NSLOT;
-            const bool in = node < tile_n1;
-            r0a[k] = in ? a.rowptr[node] - (int)tile_e0 : 0;
-            r1a[k] = in ? a.rowptr[node + 1] - (int)tile_e0 : 0;
+            const int nodec = node < tile_n1 ? node : tile_n1 - 1;
+            const int v0 = a.rowptr[nodec], v1 = a.rowptr[nodec + 1];
+            r0a[k] = node < tile_n1 ? v0 - (int)tile_e0 : 0;
+            r1a[k] = node < tile_n1 ? v1 - (int)tile_e0 : 0;
         }
         PROF_EDGE(5);
 #pragma unroll
