@@ -349,8 +349,10 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
                 for (int r = r0; r < r1; r += 4) {
                     f32x4 v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        v[i] = r + i < r1 ? *reinterpret_cast<const f32x4*>(lds + (r + i) * LDR + 4 * cq) : zero;
+                    for (int i = 0; i < 4; ++i) {         // unconditional read of a clamped row, zeroed afterwards (no predicated blocks)
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(lds + min(r + i, r1 - 1) * LDR + 4 * cq);
+                        v[i] = r + i < r1 ? t : zero;
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sum += v[i];
                 }
