@@ -219,6 +219,22 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
         par = a.nc1 & 1;
     }
 
+    // CSR row bounds of the nodes this thread reduces in the mean epilogue: fetched here, before the matrix work, so their
+    // latency is hidden (issued after the GEMM loop they were 6-12 % of the kernel); unconditional loads from clamped indices
+    constexpr int EP_NSLOT = 256 / ((NB == 1 ? 64 : 32) / 4);
+    int r0a[4] = {0, 0, 0, 0}, r1a[4] = {0, 0, 0, 0};
+    if (FUSE) {
+        const int ep_slot = tid / (256 / EP_NSLOT);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int node = tile_n0 + ep_slot + k * EP_NSLOT;
+            const int nodec = node < tile_n1 ? node : tile_n1 - 1;
+            const int v0 = a.rowptr[nodec], v1 = a.rowptr[nodec + 1];
+            r0a[k] = node < tile_n1 ? v0 - (int)tile_e0 : 0;
+            r1a[k] = node < tile_n1 ? v1 - (int)tile_e0 : 0;
+        }
+    }
+
     f32x16 y[4][NB];
     if (SPLIT) {
         acc_init_bias_scaled<NB>(a.b2, a.scales[1], hh, y);
@@ -306,16 +322,6 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
         constexpr int CPR = 32 * TPR, LDR = CPR + 4;      // channels per round, LDS row stride (dwords; 4*odd)
         constexpr int NCQ = CPR / 4, NSLOT = 256 / NCQ;
         const int cq = tid & (NCQ - 1), slot = tid / NCQ;
-        // unconditional loads from clamped indices, selected afterwards (predicated loads compile into separately waited-for blocks)
-        int r0a[4], r1a[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int node = tile_n0 + slot + k * NSLOT;
-            const int nodec = node < tile_n1 ? node : tile_n1 - 1;
-            const int v0 = a.rowptr[nodec], v1 = a.rowptr[nodec + 1];
-            r0a[k] = node < tile_n1 ? v0 - (int)tile_e0 : 0;
-            r1a[k] = node < tile_n1 ? v1 - (int)tile_e0 : 0;
-        }
         PROF_EDGE(5);
 #pragma unroll
         for (int R = 0; R < 4 / TPR; ++R) {

@@ -40,7 +40,7 @@ with torch.no_grad():
         L.msmp_debug_prof_ws(buf, 0)
         names = ['block head (edge range, bias init)', 'chunk: swish + issue loads (x4)', 'chunk: split + 24 MFMAs (x4)', 'S fragments (bpermute)',
                  'mean: swish + split + MFMAs (x4)', 'stores (x4, inside mean loop tail)', 'rotate + index loads']
-        tot = sum(buf[i] for i in range(7))
+        tot = sum(buf[i] for i in range(7)) or 1
         n_blk = 3 * 12 * 40960 / 8        # blocks seen by wave 0 of each workgroup
         print('weight-stationary edge kernel, cycles per block of wave 0: %.0f' % (tot / n_blk))
         for i, nm in enumerate(names): print(f'{nm:42s} {100.0 * buf[i] / tot:5.1f} %')
