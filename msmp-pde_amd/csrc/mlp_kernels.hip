@@ -386,6 +386,12 @@ __global__ __launch_bounds__(256, 2) void edge_mlp_kernel_occ2(EdgeArgs a) {
 }
 
 template <int NB, bool FUSE, bool FACT, bool SPLIT = false>
+__global__ __launch_bounds__(256, 3) void edge_mlp_kernel_occ3(EdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
+    edge_mlp_body<NB, FUSE, FACT, SPLIT>(a, lds);
+}
+
+template <int NB, bool FUSE, bool FACT, bool SPLIT = false>
 __global__ __launch_bounds__(256, 4) void edge_mlp_kernel_occ4(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
     edge_mlp_body<NB, FUSE, FACT, SPLIT>(a, lds);
@@ -1259,7 +1265,8 @@ extern "C" int msmp_node_project_f32(const float* h, const float* u, const float
     return check_launch("node_proj_kernel");
 }
 
-static int g_edge_occ = 4;     // 4 waves per SIMD (128 registers) measured 5 % faster than 3 (134 registers)
+static int g_edge_occ = 2;     // waves per SIMD of the default message kernel (msmp_tune "edge_occ" 2 / 3 / 4).  With the row bounds of the
+                               // epilogue prefetched, 2 (256 registers, no spill) measures 4 % faster than 4 (128 registers, 5 spilled): 2.28 vs 2.37 ms
 static int g_edge_nb = 0;    // tuning override (msmp_tune): 0 = automatic, 1 / 2 = force the tile size of the factorised kernel
 
 extern int g_edge_ws_waves;
@@ -1319,6 +1326,7 @@ static int edge_aggregate(const float* h, const float* u, const float* pos, cons
         msmp_launch_edge_ws(P, Q, rowptr, col, tgt, n_nodes, max_in_degree, packed + L.w2t, packed + L.b2, packed + L.scales, agg_out,
                             (hipStream_t)stream);
     else if (P && edges_per_tile == 128 && g_split && g_edge_occ == 4) hipLaunchKernelGGL((edge_mlp_kernel_occ4<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else if (P && edges_per_tile == 128 && g_split && g_edge_occ == 3) hipLaunchKernelGGL((edge_mlp_kernel_occ3<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (P && edges_per_tile == 128 && g_split) hipLaunchKernelGGL((edge_mlp_kernel_occ2<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (P && edges_per_tile == 128) hipLaunchKernelGGL((edge_mlp_kernel<1, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (P) hipLaunchKernelGGL((edge_mlp_kernel<2, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
