@@ -249,6 +249,29 @@ int msmp_lem_encoder_nodes_f32(const float* u, const float* pos_x, const float* 
                                int64_t n_nodes, int tw, int nv, int two_d, float dt, const float* packed, int with_mlp,
                                float* h_out, msmp_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * LEM encoder, training pair (replaces lem_cuda.forward / lem_cuda.backward as LEMFunction
+ * uses them, experiments/models_gnn.py:285-302)
+ * ------------------------------------------------------------------------------------------- */
+/* LEMFunction.forward (:287-295): the recurrence of msmp_lem_encoder_f32 (no lemoutput_mlp, exact-fp32 MFMA) that also
+ * saves what the backward needs, as the reference saves all_X / all_X2 / all_multi_scales / all_lin_new_z_state:
+ * saved [6][N][T][128] floats (msmp_lem_saved_floats) = dt*sigmoid(g2), tanh(g3), dt*sigmoid(g1), tanh(lin), y_t, z_t.
+ * xin / packed as for msmp_lem_encoder_f32; y_out [N,128] = all_y[-1]. */
+int64_t msmp_lem_saved_floats(int64_t n_nodes, int t_len);
+int msmp_lem_train_fwd_f32(const float* xin, int64_t n_nodes, int t_len, int ninp, float dt, const float* packed,
+                           float* saved, float* y_out, msmp_stream_t stream);
+/* The transposed recurrent blocks of weights / weights_lin_z for the backward kernel (16 chunks of [128][32]). */
+int64_t msmp_packed_lem_bwd_floats(void);
+int msmp_pack_lem_bwd_f32(const float* weights, const float* weights_lin_z, int ninp, float* packed_out,
+                          msmp_stream_t stream);
+/* LEMFunction.backward (:296-302), the back-propagation through time: grad_y [N,128] = dL/d all_y[-1] ->
+ * dg_out [N][T][512] = dL/d(pre-activations) per node and step, columns (g1 | g2 | g3 | lin) in the row order of
+ * `weights` then `weights_lin_z`.  The parameter gradients are GEMMs of it over the N*T rows:
+ *   d weights = dg[:, :384]^T [y_{t-1} | x_t],  d weights_lin_z = dg[:, 384:]^T [z_t | x_t],  d bias* = column sums
+ * (y, z = planes 4, 5 of `saved`).  Like the reference, no gradient of the step inputs is produced (:300-302). */
+int msmp_lem_train_bwd_f32(const float* grad_y, const float* saved, int64_t n_nodes, int t_len, float dt,
+                           const float* packed_bwd, float* dg_out, msmp_stream_t stream);
+
 /* Two-layer node MLP  out = Swish(W2 Swish(W1 x + b1) + b2)  in one launch: the `embedding_mlp` encoder of the LEM-free
  * solver classes (experiments/models_gnn.py:196-201 called at :269-270; models_gnn2D.py:66-71 called at :119-120).
  * w1 [128, k_in] (k_in = in_features of the first Linear <= 128), w2 [128,128], b* [128], reference layout.

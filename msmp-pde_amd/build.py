@@ -14,6 +14,7 @@ SOURCES = {  # file -> extra flags
     'aux_kernels.hip': [],
     # MFMA results stay in VGPRs (the activations read them with VALU; the stationary weights take the AGPRs)
     'lem_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
+    'lem_train_kernel.hip': [],
     'edge_ws_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
     'mlp2_kernel.hip': [],
     'decoder_kernel.hip': [],

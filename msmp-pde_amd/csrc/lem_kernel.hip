@@ -16,52 +16,9 @@
 // (acc = b + W[:, H:] x_t) as NS = ceil(ninp/2) extra MFMA k-steps per tile (the kernel is specialised on NS;
 // the step inputs are read from a row padded to 2*NS floats, so the time loop is branch-free).  Algorithmic work: T * 2*(H+ninp)*4H + 2*2*H*H FLOP per node
 // = 3.44 MFLOP per node at T = 25, ninp = 4 (705 GFLOP for 2048 E2 graphs): MFMA-bound.
-#include "mfma_tiles.h"
+#include "lem_layout.h"
 
 namespace msmp {
-
-constexpr int LEM_MAX_INP = 8;
-// input columns as fp16 "slot" fragments (weight-stationary kernel): [4 groups g2,g3,g1,lin][4 T][2 m][64 lanes][8 halfs]
-constexpr int LEM_WXH_FLOATS = 4 * 4 * 2 * 64 * 8 / 2;
-
-// Slot s (0..31) of the K axis of the input MFMAs pairs  A: w_hi[f] | w_hi[f] | w_lo[f]   with   B: x_hi[f] | x_lo[f] | x_hi[f]
-// for s in [0,P) | [P,2P) | [2P,3P), then  A: bias_hi | bias_lo  with  B: 1 | 1  at s = 3P, 3P + 1 (zero beyond): one K=16 MFMA
-// (P <= 4) or two (P <= 8) produce  bias + W[:, H:] x  in fp32-class accuracy from a ZERO accumulator input, so the gate
-// accumulators need no initialisation at all.
-__host__ __device__ inline int lem_slot_feature(int slot, int P) { return slot < 3 * P ? slot % P : -1; }
-__host__ __device__ inline int lem_slot_part(int slot, int P) { return slot / P; }   // 0: (hi,hi) 1: (hi,lo) 2: (lo,hi)
-
-// packed LEM blob (floats):  rec (16 chunks: g2 x4, g3 x4, g1 x4, lin x4) | mlp (8 chunks: Wa x4, Wb x4) |
-//   bias [512] (g1, g2, g3, bz in the reference's row order) |
-//   wxf [4 groups: g1,g2,g3,lin][4 T][4 s][64 lanes]: the input columns as MFMA A fragments, value
-//        = W[128*group + 32T + (lane & 31)][H + 2s + (lane >> 5)] (0 past ninp) |
-//   mlp bias [256] (ba, bb)
-//   fp16-split copies for the split kernel (mfma_tiles.h): scales [8] (2^s of W, Wz, Wa, Wb, then 2^-s) |
-//   rec_s (16 split chunks, acc order, same consumption order) | mlp_s (8 split chunks) |
-//   bias_s [512], wxf_s [4096], mlpb_s [256]: the fp32 bias / input-column fragments pre-multiplied by 2^s of their matrix |
-//   wx_h: the scaled input columns as fp16 slot fragments (see lem_slot_feature)
-struct LemLayout {
-    int64_t rec, mlp, bias, wx, mlpb, scales, rec_s, mlp_s, bias_s, wx_s, mlpb_s, wx_h, total;
-};
-
-__host__ __device__ inline LemLayout lem_layout() {
-    LemLayout L;
-    int64_t o = 0;
-    L.rec = o; o += 16 * CHUNK_FLOATS;
-    L.mlp = o; o += 8 * CHUNK_FLOATS;
-    L.bias = o; o += 4 * H;
-    L.wx = o; o += 4 * H * LEM_MAX_INP;
-    L.mlpb = o; o += 2 * H;
-    L.scales = o; o += 8;
-    L.rec_s = o; o += 16 * CHUNK_FLOATS;
-    L.mlp_s = o; o += 8 * CHUNK_FLOATS;
-    L.bias_s = o; o += 4 * H;
-    L.wx_s = o; o += 4 * H * LEM_MAX_INP;
-    L.mlpb_s = o; o += 2 * H;
-    L.wx_h = o; o += LEM_WXH_FLOATS;
-    L.total = o;
-    return L;
-}
 
 struct LemPackArgs {
     const float *w, *wz, *b, *bz, *wa, *ba, *wb, *bb;
@@ -173,13 +130,6 @@ __global__ void pack_lem_split_kernel(LemPackArgs a) {
         }
         wh[p] = v;
     }
-}
-
-__device__ __forceinline__ float tanhf_(float x) {
-    // (1 - e^{-2|x|}) / (1 + e^{-2|x|}) with the sign restored; absolute error ~1e-7
-    const float t = __builtin_amdgcn_exp2f(fabsf(x) * -2.88539008177792681472f);
-    const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
-    return copysignf(r, x);
 }
 
 struct LemArgs {

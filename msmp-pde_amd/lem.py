@@ -54,12 +54,56 @@ class LEMcuda(nn.Module):
         return y
 
 
+class _LEMTrainFunction(torch.autograd.Function):
+    """LEMFunction of the reference (experiments/models_gnn.py:285-302) on the HIP training kernels: forward =
+    msmp_lem_train_fwd_f32 (saves the per-step activations), backward = msmp_lem_train_bwd_f32 (BPTT, one launch) followed
+    by the weight-gradient GEMMs over the N*T rows.  Like the reference it returns no gradient for the step inputs."""
+
+    @staticmethod
+    def forward(ctx, owner, xin, weights, weights_lin_z, bias, bias_lin_z):
+        L = lib()
+        n, t_len, ninp = xin.shape
+        stride = L.msmp_lem_input_stride(ninp)
+        x = xin.detach().to(torch.float32)
+        x = (torch.nn.functional.pad(x, (0, stride - ninp)) if stride != ninp else x).contiguous()
+        saved = torch.empty(L.msmp_lem_saved_floats(n, t_len), dtype=torch.float32, device=x.device)
+        out = torch.empty(n, owner.nhid, dtype=torch.float32, device=x.device)
+        check(L.msmp_lem_train_fwd_f32(ptr(x), n, t_len, ninp, owner.rnn.dt, ptr(owner._pack(None)), ptr(saved), ptr(out),
+                                       current_stream()), 'msmp_lem_train_fwd_f32')
+        ctx.save_for_backward(x, saved, weights, weights_lin_z)
+        ctx.dt, ctx.ninp = owner.rnn.dt, ninp
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        L = lib()
+        x, saved, weights, weights_lin_z = ctx.saved_tensors
+        n, t_len, stride = x.shape
+        nh = weights_lin_z.shape[0]
+        blob = torch.empty(L.msmp_packed_lem_bwd_floats(), dtype=torch.float32, device=x.device)
+        w, wz = (p.detach().to(torch.float32).contiguous() for p in (weights, weights_lin_z))
+        check(L.msmp_pack_lem_bwd_f32(ptr(w), ptr(wz), ctx.ninp, ptr(blob), current_stream()), 'msmp_pack_lem_bwd_f32')
+        dg = torch.empty(n * t_len, 4 * nh, dtype=torch.float32, device=x.device)
+        g = grad_y.to(torch.float32).contiguous()
+        check(L.msmp_lem_train_bwd_f32(ptr(g), ptr(saved), n, t_len, ctx.dt, ptr(blob), ptr(dg), current_stream()),
+              'msmp_lem_train_bwd_f32')
+        planes = saved.view(6, n, t_len, nh)
+        xs = x.view(n * t_len, stride)[:, :ctx.ninp]
+        y_prev = torch.nn.functional.pad(planes[4][:, :-1], (0, 0, 1, 0)).reshape(n * t_len, nh)     # y_{t-1}, y_{-1} = 0
+        d_w = dg[:, :3 * nh].t() @ torch.cat((y_prev, xs), 1)
+        d_wz = dg[:, 3 * nh:].t() @ torch.cat((planes[5].reshape(n * t_len, nh), xs), 1)
+        d_b = dg.sum(0)
+        return None, None, d_w.to(weights.dtype), d_wz.to(weights_lin_z.dtype), d_b[:3 * nh], d_b[3 * nh:]
+
+
 class LEM(nn.Module):
     """experiments/models_gnn.py:333-342: returns all_y[-1].
 
-    `forward` is the PyTorch restatement (differentiable; used when autograd is on).  `encode` is the
-    product path for inference: the fused HIP kernel msmp_lem_encoder_f32 (recurrence + lemoutput_mlp in
-    one launch, states in registers)."""
+    `forward` is the differentiable path: on the GPU the HIP training kernels (_LEMTrainFunction; TRAIN_KERNELS = False
+    selects the PyTorch restatement LEMcuda.forward instead, which is also what CPU tensors get).  `encode` /
+    `encode_nodes` are the product path for inference: the fused HIP kernel (recurrence + lemoutput_mlp in one launch,
+    states in registers)."""
+    TRAIN_KERNELS = True
 
     def __init__(self, ninp, nhid, dt=1.):
         super().__init__()
@@ -69,7 +113,17 @@ class LEM(nn.Module):
         self._packed_key = None
 
     def forward(self, inputs):
+        """inputs [T, N, ninp] (the reference's layout) -> all_y[-1] [N, nhid]."""
+        if inputs.is_cuda and self.TRAIN_KERNELS and self.nhid == 128:
+            return self.forward_nodes(inputs.permute(1, 0, 2))
         return self.rnn(inputs)
+
+    def forward_nodes(self, xin):
+        """Same with node-major step inputs xin [N, T, ninp] (the layout the kernels read)."""
+        if not (xin.is_cuda and self.TRAIN_KERNELS and self.nhid == 128):
+            return self.rnn(xin.permute(1, 0, 2).contiguous())
+        r = self.rnn
+        return _LEMTrainFunction.apply(self, xin, r.weights, r.weights_lin_z, r.bias, r.bias_lin_z)
 
     def _pack(self, mlp):
         ps = [self.rnn.weights, self.rnn.weights_lin_z, self.rnn.bias, self.rnn.bias_lin_z]

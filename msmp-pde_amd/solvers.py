@@ -125,7 +125,7 @@ class _SolverBase(nn.Module):
             lem_in = torch.cat((pos_x[:, None, :].expand(n, t_len, 1), u[:, :, None],
                                 variables[:, None, :].expand(n, t_len, variables.shape[1])), -1)
         if grad:
-            h = self.embedding_lem(lem_in.permute(1, 0, 2).contiguous())     # differentiable PyTorch restatement
+            h = self.embedding_lem.forward_nodes(lem_in)       # HIP training kernels (recurrence forward + BPTT)
             return self.lemoutput_mlp(h)
         return self.embedding_lem.encode(lem_in, self.lemoutput_mlp)       # fused HIP kernel (recurrence + MLP)
 

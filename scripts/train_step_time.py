@@ -6,7 +6,10 @@ import torch
 import msmp_pde_amd as mp
 from msmp_pde_amd.synthetic import make_case, EXPERIMENTS
 from msmp_pde_amd.train import training_step
-for name in ('MSMP-PDE', 'Gated', 'MP-PDE'):
+from msmp_pde_amd.lem import LEM
+variants = [('MSMP-PDE', True), ('MSMP-PDE', False), ('Gated', True), ('MP-PDE', True)]      # False: LEM as PyTorch ops
+for name, lem_kernels in variants:
+    LEM.TRAIN_KERNELS = lem_kernels
     for bsz in (16, 128):
         torch.manual_seed(0)
         case = make_case('E2', bsz, seed=1, device='cuda', dtype=torch.float32)
@@ -18,4 +21,4 @@ for name in ('MSMP-PDE', 'Gated', 'MP-PDE'):
         n = 5
         for _ in range(n): loss = training_step(model, case.creator, case.u_super, case.x, case.variables, steps, 1, opt)
         torch.cuda.synchronize()
-        print(f'{name:9s} batch {bsz:4d}: {(time.perf_counter() - t0) / n * 1e3:8.2f} ms per training iteration (1 unrolled step), loss {float(loss):.4f}', flush=True)
+        print(f'{name:9s}{"" if lem_kernels else " (LEM in PyTorch)"} batch {bsz:4d}: {(time.perf_counter() - t0) / n * 1e3:8.2f} ms per training iteration (1 unrolled step), loss {float(loss):.4f}', flush=True)

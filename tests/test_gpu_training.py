@@ -23,7 +23,8 @@ def mp():
     return msmp_pde_amd
 
 
-@pytest.mark.parametrize('kind,exp', [('MP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'E2'), ('MP_PDE_Solver2DGated', 'RPU')])
+@pytest.mark.parametrize('kind,exp', [('MP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'E2'), ('MP_PDE_Solver2DGated', 'RPU'),
+                                      ('MP_PDE_SolverLEMLinGated', 'E2'), ('MP_PDE_Solver2DLEMLinGated', 'RPU')])
 def test_gradients_match_float64_oracle(mp, kind, exp):
     """d loss / d parameters of the product (HIP forward, recompute backward, fp32) against torch autograd through
     the float64 oracle, for the reference's training loss sqrt(sum (pred - y)^2) (train_helper.py:126,138)."""
@@ -110,3 +111,33 @@ def test_training_step_runs_and_decreases_loss(mp):
     losses = [T.training_step(model, c.creator, c.u_super, c.x, c.variables, [60] * 8, 1, opt).item() for _ in range(6)]
     print('losses', [round(l, 4) for l in losses])
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize('ninp,n,t_len', [(3, 77, 25), (4, 300, 25), (6, 129, 50), (8, 40, 7), (1, 33, 3)])
+def test_lem_training_kernels_match_float64_restatement(mp, ninp, n, t_len):
+    """msmp_lem_train_fwd_f32 / msmp_lem_train_bwd_f32 (through LEM.forward_nodes) against the float64 PyTorch
+    restatement of the cell (LEMcuda.forward): final state and the gradients of the four parameters (the reference's
+    LEMFunction returns exactly these, experiments/models_gnn.py:296-302).  fp32 vs float64: 1e-5 on the state
+    (the north-star tolerance), 1e-4 of the largest entry on the gradients (sums over N*T rows in fp32)."""
+    import copy
+    from msmp_pde_amd.lem import LEM
+    torch.manual_seed(11 + ninp)
+    lem = LEM(ninp, 128).cuda()
+    ref = copy.deepcopy(lem).double()
+    xin = torch.randn(n, t_len, ninp, device='cuda') * 0.7
+    w_out = torch.randn(n, 128, device='cuda')
+    y = lem.forward_nodes(xin)
+    (y * w_out).sum().backward()
+    y64 = ref.rnn(xin.double().permute(1, 0, 2).contiguous())
+    (y64 * w_out.double()).sum().backward()
+    err = (y.double() - y64).abs().max().item()
+    assert err < 1e-5, err
+    worst = 0.0
+    for (k, p), q in zip(lem.named_parameters(), ref.parameters()):
+        rel = (p.grad.double() - q.grad).abs().max().item() / q.grad.abs().max().item()
+        worst = max(worst, rel)
+        assert rel < 1e-4, (k, rel)
+    print(f'LEM train ninp={ninp} N={n} T={t_len}: state err {err:.2e}, worst gradient error {worst:.2e}')
+    # the reference layout [T, N, ninp] goes through the same kernels
+    y2 = lem(xin.permute(1, 0, 2).contiguous())
+    assert torch.equal(y2, y)
