@@ -272,6 +272,28 @@ int msmp_pack_lem_bwd_f32(const float* weights, const float* weights_lin_z, int 
 int msmp_lem_train_bwd_f32(const float* grad_y, const float* saved, int64_t n_nodes, int t_len, float dt,
                            const float* packed_bwd, float* dg_out, msmp_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training backward of a message-passing layer: the non-GEMM pieces.  The host layer
+ * re-evaluates the layer in materialised form with library GEMMs (the reference does the same through autograd over
+ * experiments/models_gnn.py:61-149) and calls these between them.
+ * ------------------------------------------------------------------------------------------- */
+/* The per-edge input of message_net_1 (models_gnn.py:69-75): out[e] = cat(h[i], h[j], u[i]-u[j], pos[i]-pos[j], vars[i]),
+ * i = tgt[e], j = col[e]; out [E, ld] with ld >= 256 + tw + 1 + nv a multiple of 4 (columns past the concat are not written). */
+int msmp_edge_concat_f32(const float* h, const float* u, const float* pos, const float* vars, const int32_t* tgt,
+                         const int32_t* col, int64_t n_edges, int tw, int nv, int ld, float* out, msmp_stream_t stream);
+/* Backward of aggr='mean' (:42,107) fused with the derivative of message_net_2's Swish:
+ *   out[e] = dagg[tgt[e]] / max(deg(tgt[e]), 1) * Swish'(a2[e]),  a2 [E,128] the pre-activation of message_net_2. */
+int msmp_mean_bwd_dswish_f32(const float* dagg, const int32_t* rowptr, const int32_t* tgt, const float* a2, int64_t n_edges,
+                             float* out, msmp_stream_t stream);
+/* Backward of msmp_instance_norm_f32 (PyG InstanceNorm, :59,66): x the normalised tensor's input, grad_y = dL/dy. */
+int msmp_instance_norm_bwd_f32(const float* x, const float* grad_y, const int32_t* graph_ptr, int64_t n_graphs, float eps,
+                               float* dx_out, msmp_stream_t stream);
+/* Backward of msmp_gate_blend_f32 (:1204-1207) through both InstanceNorms: grad_out = dL/d out ->
+ * d_gate_pre, d_main_pre (gradients of the two pre-norm tensors) and dh_out = the direct (1 - tau) path to h. */
+int msmp_gate_blend_bwd_f32(const float* grad_out, const float* h, const float* gate_pre, const float* main_pre,
+                            const int32_t* graph_ptr, int64_t n_graphs, float eps, float* d_gate_pre, float* d_main_pre,
+                            float* dh_out, msmp_stream_t stream);
+
 /* Two-layer node MLP  out = Swish(W2 Swish(W1 x + b1) + b2)  in one launch: the `embedding_mlp` encoder of the LEM-free
  * solver classes (experiments/models_gnn.py:196-201 called at :269-270; models_gnn2D.py:66-71 called at :119-120).
  * w1 [128, k_in] (k_in = in_features of the first Linear <= 128), w2 [128,128], b* [128], reference layout.

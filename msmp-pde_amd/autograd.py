@@ -1,13 +1,19 @@
-"""Autograd support for the message-passing stack (interim form of SURVEY.md section 8f row 3).
+"""Autograd support for the message-passing stack.
 
-Forward values always come from the HIP kernels (msmp_mp_layer_f32).  The backward pass is a
-RECOMPUTE: the layer is re-evaluated from its saved inputs with differentiable PyTorch-ROCm ops on the
-GPU and differentiated by torch.autograd; nothing runs on the CPU and nothing here is used by the
-inference / rollout path.  Dedicated backward kernels replace the recompute in a later round; the
-interface (mp_layer under autograd) stays.  The math below is the same restatement of
-experiments/models_gnn.py:61-149 and :1204-1207 as the kernels."""
+Forward values always come from the HIP kernels (msmp_mp_layer_f32); only the layer's inputs are saved.  The backward
+pass RECOMPUTES the layer in materialised form and differentiates it with explicit formulas: every GEMM (data and weight
+gradients, K = E or N rows) is a library call (rocBLAS through torch.addmm / mm) and everything between the GEMMs is a HIP
+glue kernel of train_kernels.hip (edge concat, mean-backward + Swish', InstanceNorm backward, gated-blend backward) or one
+elementwise library op (silu / silu_backward).  ~65 launches per gated layer pair instead of the ~190 of differentiating a
+PyTorch restatement with torch.autograd (`EXPLICIT_BACKWARD = False` keeps that path for cross-checks).  Nothing runs on
+the CPU and nothing here is used by the inference / rollout path.  The math is that of experiments/models_gnn.py:61-149
+and :1204-1207."""
 import torch
 import torch.nn.functional as F
+
+from ._lib import lib, check, ptr, current_stream
+
+EXPLICIT_BACKWARD = True
 
 
 def _swish(x):
@@ -39,6 +45,86 @@ def layer_reference(h, u, pos, variables, src, dst, batch, n_graphs, p, lin, eps
     return _instance_norm(pre, batch, n_graphs, eps)
 
 
+def _head_recompute(h, u, pos, variables, gs, p):
+    """One GNN_LayerLin / GNN_Layer up to its pre-norm update  W4 Swish(W3 [h, mean_j m_ij, var] + b3) + b4, keeping the
+    pre-activations.  p = (w1, b1, w2, b2, w3, b3, w4, b4)."""
+    L = lib()
+    w1, b1, w2, b2, w3, b3, w4, b4 = p
+    n, e, tw, nv = h.shape[0], gs.n_edges, u.shape[1], variables.shape[1]
+    k = 2 * h.shape[1] + tw + 1 + nv
+    ld = (k + 3) // 4 * 4
+    cat_e = torch.empty(e, ld, dtype=torch.float32, device=h.device)
+    if e:
+        check(L.msmp_edge_concat_f32(ptr(h), ptr(u), ptr(pos), ptr(variables), ptr(gs.tgt), ptr(gs.col), e, tw, nv, ld, ptr(cat_e),
+                                     current_stream()), 'msmp_edge_concat_f32')
+    cat_e = cat_e[:, :k]
+    a1 = torch.addmm(b1, cat_e, w1.t())
+    m1 = F.silu(a1)
+    a2 = torch.addmm(b2, m1, w2.t())
+    m2 = F.silu(a2)
+    agg = torch.zeros_like(h)                            # no in-edges anywhere: every mean is 0
+    if e:
+        check(L.msmp_scatter_mean_f32(ptr(m2), ptr(gs.rowptr), n, ptr(agg), current_stream()), 'msmp_scatter_mean_f32')
+    cat_n = torch.cat((h, agg, variables), 1)
+    a3 = torch.addmm(b3, cat_n, w3.t())
+    u1 = F.silu(a3)
+    upd = torch.addmm(b4, u1, w4.t())
+    return upd, (cat_e, a1, m1, a2, cat_n, a3, u1)
+
+
+def _head_backward(d_upd, saved, gs, p, dh):
+    """Gradients of the 8 parameters of one head; its contribution to dL/dh is accumulated into dh."""
+    L = lib()
+    cat_e, a1, m1, a2, cat_n, a3, u1 = saved
+    w1, _, w2, _, w3, _, w4, _ = p
+    hd = dh.shape[1]
+    silu_backward = torch.ops.aten.silu_backward
+    g_w4, g_b4 = d_upd.t() @ u1, d_upd.sum(0)
+    d_a3 = silu_backward(d_upd @ w4, a3)
+    g_w3, g_b3 = d_a3.t() @ cat_n, d_a3.sum(0)
+    d_cat_n = d_a3 @ w3[:, :2 * hd]                       # [dh | dagg]; the variables columns carry no gradient
+    dh += d_cat_n[:, :hd]
+    dagg = d_cat_n[:, hd:].contiguous()
+    d_a2 = torch.empty_like(a2)
+    if gs.n_edges:
+        check(L.msmp_mean_bwd_dswish_f32(ptr(dagg), ptr(gs.rowptr), ptr(gs.tgt), ptr(a2), gs.n_edges, ptr(d_a2), current_stream()),
+              'msmp_mean_bwd_dswish_f32')
+    g_w2, g_b2 = d_a2.t() @ m1, d_a2.sum(0)
+    d_a1 = silu_backward(d_a2 @ w2, a1)
+    g_w1, g_b1 = d_a1.t() @ cat_e, d_a1.sum(0)
+    d_cat_e = d_a1 @ w1[:, :2 * hd]                       # [d x_i | d x_j]
+    dh.index_add_(0, gs.tgt_long, d_cat_e[:, :hd])
+    dh.index_add_(0, gs.col_long, d_cat_e[:, hd:])
+    return g_w1, g_b1, g_w2, g_b2, g_w3, g_b3, g_w4, g_b4
+
+
+def layer_backward_explicit(gout, h, u, pos, variables, gs, params, mode_lin, gated, eps):
+    """dL/dh and dL/d params of one layer (or one gated pair) given gout = dL/d out; see the module docstring."""
+    L = lib()
+    st = current_stream()
+    gout = gout.to(torch.float32).contiguous()
+    pos1 = pos.reshape(-1)
+    params = [q.detach() for q in params]
+    if gated:
+        upd_m, sv_m = _head_recompute(h, u, pos1, variables, gs, params[:8])
+        upd_g, sv_g = _head_recompute(h, u, pos1, variables, gs, params[8:])
+        d_g, d_m, dh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        check(L.msmp_gate_blend_bwd_f32(ptr(gout), ptr(h), ptr(upd_g), ptr(upd_m), ptr(gs.graph_ptr), gs.n_graphs, eps, ptr(d_g),
+                                        ptr(d_m), ptr(dh), st), 'msmp_gate_blend_bwd_f32')
+        grads = _head_backward(d_m, sv_m, gs, params[:8], dh) + _head_backward(d_g, sv_g, gs, params[8:], dh)
+        return dh, grads
+    upd, sv = _head_recompute(h, u, pos1, variables, gs, params)
+    pre = upd if mode_lin else h + F.silu(upd)
+    dh = torch.empty_like(h)
+    check(L.msmp_instance_norm_bwd_f32(ptr(pre), ptr(gout), ptr(gs.graph_ptr), gs.n_graphs, eps, ptr(dh), st),
+          'msmp_instance_norm_bwd_f32')
+    if mode_lin:                                          # out = IN(upd): no direct path to h
+        d_upd, dh = dh, torch.zeros_like(h)
+    else:                                                 # out = IN(h + Swish(upd))
+        d_upd = torch.ops.aten.silu_backward(dh, upd)
+    return dh, _head_backward(d_upd, sv, gs, params, dh)
+
+
 class MPLayerFunction(torch.autograd.Function):
     """mp_layer with HIP forward and recompute backward.  Tensor args: h, then the main layer's 8 parameters,
     then (gated) the gate layer's 8 parameters, so autograd routes their gradients."""
@@ -54,6 +140,10 @@ class MPLayerFunction(torch.autograd.Function):
     def backward(ctx, gout):
         h, u, pos, variables, *params = ctx.saved_tensors
         gs, mode, gated, eps = ctx.meta
+        if EXPLICIT_BACKWARD:
+            with torch.no_grad():
+                dh, grads = layer_backward_explicit(gout, h, u, pos, variables, gs, params, mode == 1, gated, eps)
+            return (dh, None, None, None, None, None, None, None, None) + tuple(grads)
         src, dst = gs.col[:gs.n_edges].long(), gs.tgt[:gs.n_edges].long()
         sizes = (gs.graph_ptr[1:] - gs.graph_ptr[:-1]).long()
         batch = torch.repeat_interleave(torch.arange(gs.n_graphs, device=h.device), sizes)

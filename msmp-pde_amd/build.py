@@ -15,6 +15,7 @@ SOURCES = {  # file -> extra flags
     # MFMA results stay in VGPRs (the activations read them with VALU; the stationary weights take the AGPRs)
     'lem_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
     'lem_train_kernel.hip': [],
+    'train_kernels.hip': [],
     'edge_ws_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
     'mlp2_kernel.hip': [],
     'decoder_kernel.hip': [],

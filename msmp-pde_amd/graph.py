@@ -56,6 +56,7 @@ class GraphStructure(object):
         self.graph_ptr = torch.zeros(self.n_graphs + 1, dtype=torch.int32, device=dev)
         self.graph_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
         self.max_graph_nodes = int(counts.max().item()) if counts.numel() else 0
+        self._tgt_long = self._col_long = None
         self.rowptr = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
         self.col = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
         self.tgt = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
@@ -67,6 +68,18 @@ class GraphStructure(object):
         self.max_in_degree = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if self.n_edges else 0
         self._key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
                      batch.data_ptr(), batch._version)
+
+    @property
+    def tgt_long(self):
+        """int64 copies of the edge endpoints (torch index ops of the training backward), made once."""
+        if self._tgt_long is None:
+            self._tgt_long, self._col_long = self.tgt[:self.n_edges].long(), self.col[:self.n_edges].long()
+        return self._tgt_long
+
+    @property
+    def col_long(self):
+        self.tgt_long
+        return self._col_long
 
     def matches(self, edge_index, batch):
         return self._key == (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,

@@ -96,8 +96,11 @@ def test_data_parallel_gradients_are_exact(mp, tmp_path):
     scale = max(p.grad.abs().max().item() for p in model.parameters())
     for k, p in model.named_parameters():
         ref = p.grad.cpu()
-        rel = (dp['grads'][k] - ref).abs().max().item() / max(ref.abs().max().item(), 1e-2 * scale)
-        assert rel < 1e-4, (k, rel)     # fp32 summation-order noise only (shard sums are added in another order)
+        err = (dp['grads'][k] - ref).abs().max().item()
+        # fp32 summation-order noise only (shard sums are added in another order): relative to the tensor's own largest
+        # entry, plus an absolute floor for the gradients that are analytically zero (a bias feeding an InstanceNorm
+        # directly: column sums of the norm's backward, pure rounding residue of terms of size `scale`)
+        assert err < 1e-4 * ref.abs().max().item() + 1e-5 * scale, (k, err, ref.abs().max().item(), scale)
 
 
 def test_training_step_runs_and_decreases_loss(mp):
@@ -141,3 +144,91 @@ def test_lem_training_kernels_match_float64_restatement(mp, ninp, n, t_len):
     # the reference layout [T, N, ninp] goes through the same kernels
     y2 = lem(xin.permute(1, 0, 2).contiguous())
     assert torch.equal(y2, y)
+
+
+def _ragged(sizes):
+    gp = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device='cuda')
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).cuda()
+    return gp, batch
+
+
+def test_backward_glue_kernels_match_float64_autograd(mp):
+    """The four glue kernels of the layer backward (train_kernels.hip) through the C-ABI, each against float64 autograd of
+    the formula it differentiates; ragged graphs (1, 2, 3, 100, 130 nodes), nodes without in-edges, tw + 1 + nv odd."""
+    from msmp_pde_amd._lib import check, ptr, current_stream
+    from msmp_pde_amd import autograd as A
+    L = mp.lib()
+    g = torch.Generator(device='cpu').manual_seed(5)
+    sizes = [1, 100, 3, 130, 2]
+    gp, batch = _ragged(sizes)
+    n, b, eps = sum(sizes), len(sizes), 1e-5
+    r = lambda *s: torch.randn(*s, generator=g).cuda()
+
+    # InstanceNorm backward
+    x, gy = r(n, 128), r(n, 128)
+    dx = torch.empty_like(x)
+    check(L.msmp_instance_norm_bwd_f32(ptr(x), ptr(gy), ptr(gp), b, eps, ptr(dx), current_stream()), 'in_bwd')
+    x64 = x.double().requires_grad_(True)
+    A._instance_norm(x64, batch, b, eps).backward(gy.double())
+    multi = (batch != 0) & (batch != 4)          # 1- and 2-node graphs: y = 0 / +-1, the derivative is ill-conditioned
+    assert (dx.double() - x64.grad)[multi].abs().max().item() < 2e-5
+    assert torch.isfinite(dx).all()
+
+    # gated blend backward through both norms
+    h, gate, main, go = r(n, 128), r(n, 128), r(n, 128), r(n, 128)
+    dg, dm, dh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+    check(L.msmp_gate_blend_bwd_f32(ptr(go), ptr(h), ptr(gate), ptr(main), ptr(gp), b, eps, ptr(dg), ptr(dm), ptr(dh),
+                                    current_stream()), 'blend_bwd')
+    h64, g64, m64 = (t.double().requires_grad_(True) for t in (h, gate, main))
+    tau = torch.sigmoid(A._instance_norm(g64, batch, b, eps))
+    ((1 - tau) * h64 + tau * A._swish(A._instance_norm(m64, batch, b, eps))).backward(go.double())
+    for got, ref in ((dg, g64.grad), (dm, m64.grad), (dh, h64.grad)):
+        assert (got.double() - ref)[multi].abs().max().item() < 2e-5
+
+    # edge concat (bit-exact) and mean backward + Swish'
+    for tw, nv in ((25, 2), (25, 3), (50, 3)):
+        e = 700
+        tgt = torch.sort(torch.randint(0, n - 7, (e,), generator=g))[0].int().cuda()      # the last nodes have no in-edges
+        col = torch.randint(0, n, (e,), generator=g).int().cuda()
+        rowptr = torch.zeros(n + 1, dtype=torch.int32, device='cuda')
+        rowptr[1:] = torch.cumsum(torch.bincount(tgt.long(), minlength=n), 0).int()
+        u, pos, var = r(n, tw), r(n), r(n, nv)
+        k = 256 + tw + 1 + nv
+        ld = (k + 3) // 4 * 4
+        out = torch.full((e, ld), float('nan'), device='cuda')
+        check(L.msmp_edge_concat_f32(ptr(h), ptr(u), ptr(pos), ptr(var), ptr(tgt), ptr(col), e, tw, nv, ld, ptr(out),
+                                     current_stream()), 'edge_concat')
+        i, j = tgt.long(), col.long()
+        ref = torch.cat((h[i], h[j], u[i] - u[j], (pos[i] - pos[j])[:, None], var[i]), 1)
+        assert torch.equal(out[:, :k], ref)
+        a2, dagg = r(e, 128), r(n, 128)
+        got = torch.empty_like(a2)
+        check(L.msmp_mean_bwd_dswish_f32(ptr(dagg), ptr(rowptr), ptr(tgt), ptr(a2), e, ptr(got), current_stream()), 'mean_bwd')
+        a64 = a2.double().requires_grad_(True)
+        A._seg_mean(A._swish(a64), i, n).backward(dagg.double())
+        assert (got.double() - a64.grad).abs().max().item() < 1e-5
+
+
+def test_explicit_backward_equals_autograd_recompute(mp):
+    """The explicit layer backward (library GEMMs + glue kernels) against torch.autograd over the PyTorch restatement of
+    the same layer, both fp32 on the GPU, for the three layer forms (residual-Swish, Lin, gated pair)."""
+    from msmp_pde_amd import autograd as A
+    from msmp_pde_amd.synthetic import make_case
+    c = make_case('E2', 5, seed=3, device='cuda', dtype=torch.float32)
+    for name in ('MP-PDE', 'Gated'):
+        grads = []
+        for explicit in (True, False):
+            A.EXPLICIT_BACKWARD = explicit
+            try:
+                torch.manual_seed(1)
+                model = mp.MODEL_NAMES[name](c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=2).cuda()
+                data, labels = c.creator.create_data(c.u_super, [60] * 5)
+                graph = c.creator.create_graph(data, labels, c.x, c.variables, [60] * 5)
+                torch.sqrt(((model(graph) - graph.y) ** 2).sum()).backward()
+                grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+            finally:
+                A.EXPLICIT_BACKWARD = True
+        scale = max(v.abs().max().item() for v in grads[1].values())
+        for k in grads[0]:
+            err = (grads[0][k] - grads[1][k]).abs().max().item()
+            assert err < 1e-4 * grads[1][k].abs().max().item() + 1e-5 * scale, (name, k, err)
