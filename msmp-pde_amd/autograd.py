@@ -62,7 +62,7 @@ def _head_recompute(h, u, pos, variables, gs, p):
     m1 = F.silu(a1)
     a2 = torch.addmm(b2, m1, w2.t())
     m2 = F.silu(a2)
-    agg = torch.zeros_like(h)                            # no in-edges anywhere: every mean is 0
+    agg = torch.empty_like(h) if e else torch.zeros_like(h)      # no in-edges anywhere: every mean is 0
     if e:
         check(L.msmp_scatter_mean_f32(ptr(m2), ptr(gs.rowptr), n, ptr(agg), current_stream()), 'msmp_scatter_mean_f32')
     cat_n = torch.cat((h, agg, variables), 1)
@@ -72,16 +72,40 @@ def _head_recompute(h, u, pos, variables, gs, p):
     return upd, (cat_e, a1, m1, a2, cat_n, a3, u1)
 
 
+def grad_weights(pairs):
+    """[(A [R,128] = dL/d pre-activation, B [R,k2] = the linear layer's input)] -> [dW [128,k2], db [128], ...] through
+    msmp_grad_weights_f32 (all pairs in one call; row-split exact-fp32 MFMA partials, deterministic)."""
+    import ctypes
+    L = lib()
+    n = len(pairs)
+    a = [x.contiguous() for x, _ in pairs]
+    b = [y if y.stride(1) == 1 else y.contiguous() for _, y in pairs]
+    rows = (ctypes.c_int64 * n)(*[x.shape[0] for x in a])
+    k2 = (ctypes.c_int * n)(*[y.shape[1] for y in b])
+    ldb = (ctypes.c_int * n)(*[y.stride(0) for y in b])
+    outs = [torch.empty(a[i].shape[1], b[i].shape[1] + 1, dtype=torch.float32, device=a[i].device) for i in range(n)]
+    ws_floats = L.msmp_grad_weights_workspace_floats(n, rows, k2)
+    if ws_floats < 0:
+        raise ValueError('grad_weights: unsupported shapes')
+    ws = torch.empty(ws_floats, dtype=torch.float32, device=a[0].device)
+    vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    check(L.msmp_grad_weights_f32(n, vp(a), vp(b), rows, ldb, k2, vp(outs), ptr(ws), ws_floats, current_stream()),
+          'msmp_grad_weights_f32')
+    res = []
+    for o in outs:
+        res += [o[:, :-1], o[:, -1]]
+    return res
+
+
 def _head_backward(d_upd, saved, gs, p, dh):
-    """Gradients of the 8 parameters of one head; its contribution to dL/dh is accumulated into dh."""
+    """Back-propagates dL/d(pre-norm update) of one head to dL/dh (accumulated into dh) and returns the four
+    (dL/d pre-activation, layer input) pairs of its linear layers, in parameter order, for grad_weights."""
     L = lib()
     cat_e, a1, m1, a2, cat_n, a3, u1 = saved
     w1, _, w2, _, w3, _, w4, _ = p
     hd = dh.shape[1]
     silu_backward = torch.ops.aten.silu_backward
-    g_w4, g_b4 = d_upd.t() @ u1, d_upd.sum(0)
     d_a3 = silu_backward(d_upd @ w4, a3)
-    g_w3, g_b3 = d_a3.t() @ cat_n, d_a3.sum(0)
     d_cat_n = d_a3 @ w3[:, :2 * hd]                       # [dh | dagg]; the variables columns carry no gradient
     dh += d_cat_n[:, :hd]
     dagg = d_cat_n[:, hd:].contiguous()
@@ -89,13 +113,23 @@ def _head_backward(d_upd, saved, gs, p, dh):
     if gs.n_edges:
         check(L.msmp_mean_bwd_dswish_f32(ptr(dagg), ptr(gs.rowptr), ptr(gs.tgt), ptr(a2), gs.n_edges, ptr(d_a2), current_stream()),
               'msmp_mean_bwd_dswish_f32')
-    g_w2, g_b2 = d_a2.t() @ m1, d_a2.sum(0)
     d_a1 = silu_backward(d_a2 @ w2, a1)
-    g_w1, g_b1 = d_a1.t() @ cat_e, d_a1.sum(0)
     d_cat_e = d_a1 @ w1[:, :2 * hd]                       # [d x_i | d x_j]
     dh.index_add_(0, gs.tgt_long, d_cat_e[:, :hd])
     dh.index_add_(0, gs.col_long, d_cat_e[:, hd:])
-    return g_w1, g_b1, g_w2, g_b2, g_w3, g_b3, g_w4, g_b4
+    return [(d_a1, cat_e), (d_a2, m1), (d_a3, cat_n), (d_upd, u1)]
+
+
+def _param_grads(pairs, n_edges):
+    if n_edges:
+        return grad_weights(pairs)
+    res = []                                              # no edges: the message layers get zero gradients
+    for k, (a, b) in enumerate(pairs):
+        if a.shape[0]:
+            res += grad_weights([(a, b)])
+        else:
+            res += [a.new_zeros(a.shape[1], b.shape[1]), a.new_zeros(a.shape[1])]
+    return res
 
 
 def layer_backward_explicit(gout, h, u, pos, variables, gs, params, mode_lin, gated, eps):
@@ -111,8 +145,8 @@ def layer_backward_explicit(gout, h, u, pos, variables, gs, params, mode_lin, ga
         d_g, d_m, dh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
         check(L.msmp_gate_blend_bwd_f32(ptr(gout), ptr(h), ptr(upd_g), ptr(upd_m), ptr(gs.graph_ptr), gs.n_graphs, eps, ptr(d_g),
                                         ptr(d_m), ptr(dh), st), 'msmp_gate_blend_bwd_f32')
-        grads = _head_backward(d_m, sv_m, gs, params[:8], dh) + _head_backward(d_g, sv_g, gs, params[8:], dh)
-        return dh, grads
+        pairs = _head_backward(d_m, sv_m, gs, params[:8], dh) + _head_backward(d_g, sv_g, gs, params[8:], dh)
+        return dh, _param_grads(pairs, gs.n_edges)
     upd, sv = _head_recompute(h, u, pos1, variables, gs, params)
     pre = upd if mode_lin else h + F.silu(upd)
     dh = torch.empty_like(h)
@@ -122,7 +156,7 @@ def layer_backward_explicit(gout, h, u, pos, variables, gs, params, mode_lin, ga
         d_upd, dh = dh, torch.zeros_like(h)
     else:                                                 # out = IN(h + Swish(upd))
         d_upd = torch.ops.aten.silu_backward(dh, upd)
-    return dh, _head_backward(d_upd, sv, gs, params, dh)
+    return dh, _param_grads(_head_backward(d_upd, sv, gs, params, dh), gs.n_edges)
 
 
 class MPLayerFunction(torch.autograd.Function):

@@ -181,3 +181,147 @@ extern "C" int msmp_gate_blend_bwd_f32(const float* grad_out, const float* h, co
                        main_pre, graph_ptr, eps, d_gate_pre, d_main_pre, dh_out);
     return check_launch("gate_blend_bwd_kernel");
 }
+
+// ----------------------------------------------------------------------------------------------
+// Weight gradients:  dW[m][n] = sum_r A[r][m] B[r][n]  and  db[m] = sum_r A[r][m]  for up to 8 (A, B) pairs in one call
+// (A [R,128] = gradient of a pre-activation, B [R, >= k2] = the input of that linear layer, R = E or N rows).
+// These GEMMs are 128 x k2 outputs with a reduction over R >> 1000 rows: the library runs them on 36 workgroups
+// (63 us each at R = 9 408); here the rows are split over workgroups (exact-fp32 MFMA partial products, the bias column
+// as a virtual all-ones column k2 of B), and a second kernel sums the partials in a fixed order (deterministic).
+// ----------------------------------------------------------------------------------------------
+namespace msmp {
+
+constexpr int GW_MAX_JOBS = 8;
+struct GradWeightJob {
+    const float* a;      // [rows, 128]
+    const float* b;      // [rows, ldb], columns 0..k2-1 used
+    float* out;          // [128, k2 + 1]: dW | db
+    float* partial;      // [splits][128][32 * nt]
+    int rows, ldb, k2, nt, rows_per_split, splits, first_block;
+};
+struct GradWeightArgs {
+    GradWeightJob job[GW_MAX_JOBS];
+    int n_jobs;
+};
+
+template <int NT>
+__device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int split, int wave, int lane) {
+    const int m = lane & 31, kk = lane >> 5;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int r0 = split * j.rows_per_split, r1 = min(r0 + j.rows_per_split, j.rows);
+    // 4 k-steps (8 rows) per iteration with all 4 (1 + NT) loads issued before the first MFMA: the loop is bound by load
+    // latency otherwise.  Every lane runs the same trip count; rows past r1 are clamped and contribute 0.
+    constexpr int U = 4;
+    for (int rb = r0; rb < r1; rb += 2 * U) {
+        float av[U], bv[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = rb + 2 * u + kk;
+            const bool in = r < r1;
+            const int rc = in ? r : r1 - 1;
+            av[u] = j.a[(size_t)rc * H + 32 * wave + m];
+            av[u] = in ? av[u] : 0.f;
+            const float* brow = j.b + (size_t)rc * j.ldb;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = 32 * t + m;
+                const int cc = c < j.k2 ? c : 0;
+                const float b = brow[cc];
+                bv[u][t] = c < j.k2 ? b : (c == j.k2 ? 1.0f : 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+    }
+    float* p = j.partial + (size_t)split * H * (32 * NT);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[(size_t)(32 * wave + acc_row(r, kk)) * (32 * NT) + 32 * t + m] = acc[t][r];
+}
+
+__global__ __launch_bounds__(256) void grad_weight_kernel(GradWeightArgs a) {
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < GW_MAX_JOBS; ++i)
+        if (i < a.n_jobs && (int)blockIdx.x >= a.job[i].first_block) ji = i;
+    const GradWeightJob& j = a.job[ji];
+    const int split = blockIdx.x - j.first_block, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    switch (j.nt) {
+        case 5: grad_weight_body<5>(j, split, wave, lane); break;
+        case 9: grad_weight_body<9>(j, split, wave, lane); break;
+        default: grad_weight_body<10>(j, split, wave, lane); break;
+    }
+}
+
+// out[row][col] = sum over splits, in split order; grid.y = job
+__global__ __launch_bounds__(256) void grad_weight_reduce_kernel(GradWeightArgs a) {
+    const GradWeightJob& j = a.job[blockIdx.y];
+    const int w = j.k2 + 1, ldp = 32 * j.nt, total = H * w;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+        const int row = p / w, c = p - row * w;
+        const float* src = j.partial + (size_t)row * ldp + c;
+        float s = 0.f;
+        for (int k = 0; k < j.splits; ++k) s += src[(size_t)k * H * ldp];
+        j.out[p] = s;
+    }
+}
+
+static int gw_tiles(int k2) { const int t = (k2 + 1 + 31) / 32; return t <= 5 ? 5 : t <= 9 ? 9 : t <= 10 ? 10 : -1; }
+static int gw_rows_per_split(int64_t rows) {
+    int64_t rps = 128;
+    while ((rows + rps - 1) / rps > 512) rps *= 2;
+    return (int)rps;
+}
+
+}  // namespace msmp
+
+extern "C" int64_t msmp_grad_weights_workspace_floats(int n_jobs, const int64_t* rows, const int* k2) {
+    if (n_jobs < 1 || n_jobs > GW_MAX_JOBS || !rows || !k2) return -1;
+    int64_t total = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const int nt = gw_tiles(k2[i]);
+        if (nt < 0 || rows[i] < 1) return -1;
+        const int rps = gw_rows_per_split(rows[i]);
+        total += ((rows[i] + rps - 1) / rps) * H * 32 * nt;
+    }
+    return total;
+}
+
+extern "C" int msmp_grad_weights_f32(int n_jobs, const float* const* a, const float* const* b, const int64_t* rows, const int* ldb,
+                                     const int* k2, float* const* out, float* workspace, int64_t workspace_floats,
+                                     msmp_stream_t stream) {
+    MSMP_REQUIRE(n_jobs >= 1 && n_jobs <= GW_MAX_JOBS, MSMP_ERR_ARG, "msmp_grad_weights_f32: n_jobs=%d not in 1..%d", n_jobs, GW_MAX_JOBS);
+    MSMP_REQUIRE(a && b && rows && ldb && k2 && out && workspace, MSMP_ERR_ARG, "msmp_grad_weights_f32: null pointer");
+    GradWeightArgs args;
+    args.n_jobs = n_jobs;
+    int64_t used = 0;
+    int blocks = 0, max_w = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        MSMP_REQUIRE(a[i] && b[i] && out[i], MSMP_ERR_ARG, "msmp_grad_weights_f32: null pointer in job %d", i);
+        MSMP_REQUIRE(rows[i] >= 1 && rows[i] < (1L << 31) && k2[i] >= 1 && ldb[i] >= k2[i], MSMP_ERR_ARG, "msmp_grad_weights_f32: bad sizes in job %d", i);
+        const int nt = gw_tiles(k2[i]);
+        MSMP_REQUIRE(nt > 0, MSMP_ERR_UNSUPPORTED, "msmp_grad_weights_f32: k2=%d > 319", k2[i]);
+        GradWeightJob& j = args.job[i];
+        j.a = a[i]; j.b = b[i]; j.out = out[i]; j.partial = workspace + used;
+        j.rows = (int)rows[i]; j.ldb = ldb[i]; j.k2 = k2[i]; j.nt = nt;
+        j.rows_per_split = gw_rows_per_split(rows[i]);
+        j.splits = (j.rows + j.rows_per_split - 1) / j.rows_per_split;
+        j.first_block = blocks;
+        blocks += j.splits;
+        used += (int64_t)j.splits * H * 32 * nt;
+        max_w = k2[i] + 1 > max_w ? k2[i] + 1 : max_w;
+    }
+    for (int i = n_jobs; i < GW_MAX_JOBS; ++i) args.job[i] = args.job[0];
+    MSMP_REQUIRE(used <= workspace_floats, MSMP_ERR_ARG, "msmp_grad_weights_f32: workspace of %ld floats, need %ld", (long)workspace_floats, (long)used);
+    hipLaunchKernelGGL(grad_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, args);
+    hipLaunchKernelGGL(grad_weight_reduce_kernel, dim3((unsigned)((H * max_w + 255) / 256), (unsigned)n_jobs), dim3(256), 0,
+                       (hipStream_t)stream, args);
+    return check_launch("grad_weight_kernel");
+}
