@@ -295,12 +295,12 @@ int msmp_gate_blend_bwd_f32(const float* grad_out, const float* h, const float* 
                             float* dh_out, msmp_stream_t stream);
 
 /* Weight and bias gradients of up to 8 linear layers in one call (two launches):
- *   out[i] [128, k2+1] = ( a[i]^T b[i][:, :k2] | column sums of a[i] ),  a[i] [rows, 128] = dL/d(pre-activation),
- *   b[i] [rows, ldb] = that layer's input (row stride ldb >= k2 <= 319).  Exact-fp32 MFMA partial products over row
+ *   out[i] [128, k2+1] = ( a[i]^T b[i][:, :k2] | column sums of a[i] ),  a[i] [rows, 128] (row stride lda >= 128) =
+ *   dL/d(pre-activation), b[i] [rows, k2] (row stride ldb >= k2, k2 <= 319) = that layer's input.  Exact-fp32 MFMA partial products over row
  *   splits, summed in a fixed order (deterministic).  workspace: msmp_grad_weights_workspace_floats floats. */
 int64_t msmp_grad_weights_workspace_floats(int n_jobs, const int64_t* rows, const int* k2);
-int msmp_grad_weights_f32(int n_jobs, const float* const* a, const float* const* b, const int64_t* rows, const int* ldb,
-                          const int* k2, float* const* out, float* workspace, int64_t workspace_floats, msmp_stream_t stream);
+int msmp_grad_weights_f32(int n_jobs, const float* const* a, const float* const* b, const int64_t* rows, const int* lda,
+                          const int* ldb, const int* k2, float* const* out, float* workspace, int64_t workspace_floats, msmp_stream_t stream);
 
 /* Two-layer node MLP  out = Swish(W2 Swish(W1 x + b1) + b2)  in one launch: the `embedding_mlp` encoder of the LEM-free
  * solver classes (experiments/models_gnn.py:196-201 called at :269-270; models_gnn2D.py:66-71 called at :119-120).

@@ -73,15 +73,16 @@ def _head_recompute(h, u, pos, variables, gs, p):
 
 
 def grad_weights(pairs):
-    """[(A [R,128] = dL/d pre-activation, B [R,k2] = the linear layer's input)] -> [dW [128,k2], db [128], ...] through
+    """[(A [R,128] = dL/d pre-activation, B [R,k2] = the linear layer's input; row-strided views are fine)] -> [dW [128,k2], db [128], ...] through
     msmp_grad_weights_f32 (all pairs in one call; row-split exact-fp32 MFMA partials, deterministic)."""
     import ctypes
     L = lib()
     n = len(pairs)
-    a = [x.contiguous() for x, _ in pairs]
+    a = [x if x.stride(1) == 1 else x.contiguous() for x, _ in pairs]
     b = [y if y.stride(1) == 1 else y.contiguous() for _, y in pairs]
     rows = (ctypes.c_int64 * n)(*[x.shape[0] for x in a])
     k2 = (ctypes.c_int * n)(*[y.shape[1] for y in b])
+    lda = (ctypes.c_int * n)(*[x.stride(0) for x in a])
     ldb = (ctypes.c_int * n)(*[y.stride(0) for y in b])
     outs = [torch.empty(a[i].shape[1], b[i].shape[1] + 1, dtype=torch.float32, device=a[i].device) for i in range(n)]
     ws_floats = L.msmp_grad_weights_workspace_floats(n, rows, k2)
@@ -89,7 +90,7 @@ def grad_weights(pairs):
         raise ValueError('grad_weights: unsupported shapes')
     ws = torch.empty(ws_floats, dtype=torch.float32, device=a[0].device)
     vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
-    check(L.msmp_grad_weights_f32(n, vp(a), vp(b), rows, ldb, k2, vp(outs), ptr(ws), ws_floats, current_stream()),
+    check(L.msmp_grad_weights_f32(n, vp(a), vp(b), rows, lda, ldb, k2, vp(outs), ptr(ws), ws_floats, current_stream()),
           'msmp_grad_weights_f32')
     res = []
     for o in outs:

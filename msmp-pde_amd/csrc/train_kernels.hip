@@ -184,7 +184,7 @@ extern "C" int msmp_gate_blend_bwd_f32(const float* grad_out, const float* h, co
 
 // ----------------------------------------------------------------------------------------------
 // Weight gradients:  dW[m][n] = sum_r A[r][m] B[r][n]  and  db[m] = sum_r A[r][m]  for up to 8 (A, B) pairs in one call
-// (A [R,128] = gradient of a pre-activation, B [R, >= k2] = the input of that linear layer, R = E or N rows).
+// (A [R,128] (row stride lda) = gradient of a pre-activation, B [R, >= k2] = the input of that linear layer, R = E or N rows).
 // These GEMMs are 128 x k2 outputs with a reduction over R >> 1000 rows: the library runs them on 36 workgroups
 // (63 us each at R = 9 408); here the rows are split over workgroups (exact-fp32 MFMA partial products, the bias column
 // as a virtual all-ones column k2 of B), and a second kernel sums the partials in a fixed order (deterministic).
@@ -193,11 +193,11 @@ namespace msmp {
 
 constexpr int GW_MAX_JOBS = 8;
 struct GradWeightJob {
-    const float* a;      // [rows, 128]
+    const float* a;      // [rows, lda], columns 0..127 used
     const float* b;      // [rows, ldb], columns 0..k2-1 used
     float* out;          // [128, k2 + 1]: dW | db
     float* partial;      // [splits][128][32 * nt]
-    int rows, ldb, k2, nt, rows_per_split, splits, first_block;
+    int rows, lda, ldb, k2, nt, rows_per_split, splits, first_block;
 };
 struct GradWeightArgs {
     GradWeightJob job[GW_MAX_JOBS];
@@ -223,7 +223,7 @@ __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int spl
             const int r = rb + 2 * u + kk;
             const bool in = r < r1;
             const int rc = in ? r : r1 - 1;
-            av[u] = j.a[(size_t)rc * H + 32 * wave + m];
+            av[u] = j.a[(size_t)rc * j.lda + 32 * wave + m];
             av[u] = in ? av[u] : 0.f;
             const float* brow = j.b + (size_t)rc * j.ldb;
 #pragma unroll
@@ -294,23 +294,23 @@ extern "C" int64_t msmp_grad_weights_workspace_floats(int n_jobs, const int64_t*
     return total;
 }
 
-extern "C" int msmp_grad_weights_f32(int n_jobs, const float* const* a, const float* const* b, const int64_t* rows, const int* ldb,
-                                     const int* k2, float* const* out, float* workspace, int64_t workspace_floats,
+extern "C" int msmp_grad_weights_f32(int n_jobs, const float* const* a, const float* const* b, const int64_t* rows, const int* lda,
+                                     const int* ldb, const int* k2, float* const* out, float* workspace, int64_t workspace_floats,
                                      msmp_stream_t stream) {
     MSMP_REQUIRE(n_jobs >= 1 && n_jobs <= GW_MAX_JOBS, MSMP_ERR_ARG, "msmp_grad_weights_f32: n_jobs=%d not in 1..%d", n_jobs, GW_MAX_JOBS);
-    MSMP_REQUIRE(a && b && rows && ldb && k2 && out && workspace, MSMP_ERR_ARG, "msmp_grad_weights_f32: null pointer");
+    MSMP_REQUIRE(a && b && rows && lda && ldb && k2 && out && workspace, MSMP_ERR_ARG, "msmp_grad_weights_f32: null pointer");
     GradWeightArgs args;
     args.n_jobs = n_jobs;
     int64_t used = 0;
     int blocks = 0, max_w = 0;
     for (int i = 0; i < n_jobs; ++i) {
         MSMP_REQUIRE(a[i] && b[i] && out[i], MSMP_ERR_ARG, "msmp_grad_weights_f32: null pointer in job %d", i);
-        MSMP_REQUIRE(rows[i] >= 1 && rows[i] < (1L << 31) && k2[i] >= 1 && ldb[i] >= k2[i], MSMP_ERR_ARG, "msmp_grad_weights_f32: bad sizes in job %d", i);
+        MSMP_REQUIRE(rows[i] >= 1 && rows[i] < (1L << 31) && k2[i] >= 1 && ldb[i] >= k2[i] && lda[i] >= H, MSMP_ERR_ARG, "msmp_grad_weights_f32: bad sizes in job %d", i);
         const int nt = gw_tiles(k2[i]);
         MSMP_REQUIRE(nt > 0, MSMP_ERR_UNSUPPORTED, "msmp_grad_weights_f32: k2=%d > 319", k2[i]);
         GradWeightJob& j = args.job[i];
         j.a = a[i]; j.b = b[i]; j.out = out[i]; j.partial = workspace + used;
-        j.rows = (int)rows[i]; j.ldb = ldb[i]; j.k2 = k2[i]; j.nt = nt;
+        j.rows = (int)rows[i]; j.lda = lda[i]; j.ldb = ldb[i]; j.k2 = k2[i]; j.nt = nt;
         j.rows_per_split = gw_rows_per_split(rows[i]);
         j.splits = (j.rows + j.rows_per_split - 1) / j.rows_per_split;
         j.first_block = blocks;

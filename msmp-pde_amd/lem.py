@@ -90,10 +90,12 @@ class _LEMTrainFunction(torch.autograd.Function):
         planes = saved.view(6, n, t_len, nh)
         xs = x.view(n * t_len, stride)[:, :ctx.ninp]
         y_prev = torch.nn.functional.pad(planes[4][:, :-1], (0, 0, 1, 0)).reshape(n * t_len, nh)     # y_{t-1}, y_{-1} = 0
-        d_w = dg[:, :3 * nh].t() @ torch.cat((y_prev, xs), 1)
-        d_wz = dg[:, 3 * nh:].t() @ torch.cat((planes[5].reshape(n * t_len, nh), xs), 1)
-        d_b = dg.sum(0)
-        return None, None, d_w.to(weights.dtype), d_wz.to(weights_lin_z.dtype), d_b[:3 * nh], d_b[3 * nh:]
+        yx = torch.cat((y_prev, xs), 1)
+        zx = torch.cat((planes[5].reshape(n * t_len, nh), xs), 1)
+        from .autograd import grad_weights          # weight / bias gradients: sums over the N*T rows (msmp_grad_weights_f32)
+        g = grad_weights([(dg[:, :nh], yx), (dg[:, nh:2 * nh], yx), (dg[:, 2 * nh:3 * nh], yx), (dg[:, 3 * nh:], zx)])
+        d_w, d_b = torch.cat(g[0:6:2], 0), torch.cat(g[1:6:2], 0)
+        return None, None, d_w.to(weights.dtype), g[6].to(weights_lin_z.dtype), d_b, g[7]
 
 
 class LEM(nn.Module):
