@@ -17,7 +17,8 @@
 //
 // Both kernels use the channel-major exact-fp32 MFMA scheme of lem_encoder_kernel (one node per lane, the carried
 // tensors in accumulator layout for all T steps, weight chunks of [128][32] streamed through the double-buffered LDS
-// pipeline); the backward consumes chunks of the TRANSPOSED recurrent blocks (msmp_pack_lem_bwd_f32).  Saved tensors are
+// pipeline), with the four channel tiles of a 32-node block on four waves (see "workgroup shape" below); the backward
+// consumes chunks of the TRANSPOSED recurrent blocks (msmp_pack_lem_bwd_f32).  Saved tensors are
 // node-major [6][N][T][128] (a2, c, a1, d, y', z'), so each is directly the row matrix of the weight-gradient GEMMs.
 // Sized for training batches (tens of graphs: the forward + backward pair replaces ~2 000 PyTorch launches); at
 // N = 1 600, T = 25 the six saved tensors are 123 MB.
@@ -40,19 +41,7 @@ struct LemTrainArgs {
     float* out;          // [N,128] = y_T
 };
 
-// one tile pair of a node row <-> accumulator registers: register 4q+m of tile T is channel 32T + 8q + 4hh + m
-__device__ __forceinline__ void row_store(float* row_hh, const f32x16 (&v)[4][1]) {
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 p;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) p[m] = v[T][0][4 * q + m];
-            *reinterpret_cast<f32x4*>(row_hh + 32 * T + 8 * q) = p;
-        }
-}
-
+// one tile of a node row <-> accumulator registers: register 4q+m of tile T is channel 32T + 8q + 4hh + m
 __device__ __forceinline__ void tile_load(const float* row_hh, int T, f32x16& v) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -72,26 +61,51 @@ __device__ __forceinline__ void tile_store(float* row_hh, int T, const f32x16& v
     }
 }
 
-template <int NS>
-__device__ __forceinline__ void lem_train_acc_init(const LemTrainArgs& a, int grp, int lane, int hh, const float (&x)[2 * NS],
-                                                   f32x16 (&acc)[4][1]) {
-    acc_init_bias<1>(a.bias + H * grp, hh, acc);
-    const float* wf = a.wx + (size_t)grp * 1024 + lane;
+// ---- workgroup shape -------------------------------------------------------------------------------------------------
+// 256 threads = ONE block of 32 nodes; wave ct owns channel tile ct (32 of the 128 channels) of every tensor, so the
+// 25-step dependency chain of a wave is 16 MFMAs per weight chunk instead of 64 (the chain, not the throughput, sets the
+// time at training batch sizes: 1 600 nodes = 50 workgroups).  A GEMM needs all 128 channels of its B operand: the
+// operand tensor is published in LDS as xs[channel][node] (row stride 40 floats: the two half-waves of a B fragment read
+// rows 4 apart = 32 banks apart, conflict-free) and every wave reads its fragments from there.
+constexpr int XS = 40;
+
+__device__ __forceinline__ void publish_tile(float* xs, int ct, int c, int hh, const f32x16& v) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const float b = hh ? x[2 * s + 1] : x[2 * s];
+    for (int r = 0; r < 16; ++r) xs[(32 * ct + acc_row(r, hh)) * XS + c] = v[r];
+}
+
+// acc (tile ct) += W_chunk[32 ct .., k] * X[32 kc + k][node]  for the 32 k of one staged chunk
+__device__ __forceinline__ void mma_chunk_tile(const float* wl, const float* xs, int ct, int kc, int c, int hh, f32x16& acc) {
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
-            acc[T][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[(T * 4 + s) * 64], b, acc[T][0], 0, 0, 0);
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wl + (32 * ct + c) * LDW + 8 * q + 4 * hh);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], xs[(32 * kc + 8 * q + 4 * hh + m) * XS + c], acc, 0, 0, 0);
     }
 }
 
-// one GEMM group: 4 chunks (K = 128), B = the accumulator-layout tensor X; the stream continues with chunk BASE + 4 (or NEXT)
-#define LEM_TRAIN_GROUP(SRC, X, ACC, BASE, NEXT_AFTER_LAST)                                              \
+// acc (tile ct) = bias + W[:, H:H+ninp] x_t  (the input columns as NS fp32 MFMA k-steps)
+template <int NS>
+__device__ __forceinline__ void tile_init(const LemTrainArgs& a, int grp, int ct, int lane, int hh, const float (&x)[2 * NS], f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + H * grp + 32 * ct + 8 * q + 4 * hh);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[4 * q + m] = bv[m];
+    }
+    const float* wf = a.wx + (size_t)grp * 1024 + lane;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[(ct * 4 + s) * 64], hh ? x[2 * s + 1] : x[2 * s], acc, 0, 0, 0);
+}
+
+// one GEMM group: 4 chunks (K = 128) against the tensor currently published in xs; the chunk after the last is NEXT
+#define LEM_TRAIN_GROUP(SRC, ACC, BASE, NEXT_AFTER_LAST)                                                 \
     _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                   \
         const float* nxt = kc < 3 ? (SRC) + (size_t)((BASE) + kc + 1) * CHUNK_FLOATS : (NEXT_AFTER_LAST); \
         wstage_load(ws, nxt, tid);                                                                       \
-        mma_chunk_from_acc<1>(lds + (((BASE) + kc) & 1) * H * LDW, c, hh, X[kc], ACC);                   \
+        mma_chunk_tile(lds + (((BASE) + kc) & 1) * H * LDW, xs, ct, kc, c, hh, ACC);                     \
         wstage_store(ws, lds + (((BASE) + kc + 1) & 1) * H * LDW, tid);                                  \
         __syncthreads();                                                                                 \
     }
@@ -99,20 +113,20 @@ __device__ __forceinline__ void lem_train_acc_init(const LemTrainArgs& a, int gr
 template <int NS>
 __global__ __launch_bounds__(256) void lem_train_fwd_kernel(LemTrainArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float xs[H * XS];
+    const int tid = threadIdx.x, lane = tid & 63, ct = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
-    const long n = (long)blockIdx.x * 128 + wave * 32 + c;
+    const long n = (long)blockIdx.x * 32 + c;
     const bool live = n < a.n_nodes;
     const long nc = live ? n : a.n_nodes - 1;
     const float* xrow = a.xin + (size_t)nc * a.t_len * (2 * NS);
     const size_t plane = (size_t)a.n_nodes * a.t_len * H;
     float* srow = a.saved + (size_t)nc * a.t_len * H + 4 * hh;
 
-    f32x16 y[4][1], z[4][1], g[4][1], acc[4][1];
+    f32x16 y, z, g, acc;
 #pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { y[T][0][r] = 0.f; z[T][0][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { y[r] = 0.f; z[r] = 0.f; }
+    publish_tile(xs, ct, c, hh, y);
 
     WStage ws;
     wstage_load(ws, a.rec, tid);
@@ -125,42 +139,38 @@ __global__ __launch_bounds__(256) void lem_train_fwd_kernel(LemTrainArgs a) {
         for (int f = 0; f < 2 * NS; ++f) x[f] = xrow[t * (2 * NS) + f];
         float* st = srow + (size_t)t * H;
 
-        lem_train_acc_init<NS>(a, 1, lane, hh, x, g);                 // g2 -> a2
-        LEM_TRAIN_GROUP(a.rec, y, g, 0, a.rec + 4 * CHUNK_FLOATS)
+        tile_init<NS>(a, 1, ct, lane, hh, x, g);                      // g2 -> a2            (xs = y)
+        LEM_TRAIN_GROUP(a.rec, g, 0, a.rec + 4 * CHUNK_FLOATS)
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
+        for (int r = 0; r < 16; ++r) g[r] = a.dt * sigmoidf_(g[r]);
+        if (live) tile_store(st + SV_A2 * plane, ct, g);
+        tile_init<NS>(a, 2, ct, lane, hh, x, acc);                    // g3 -> c, z'
+        LEM_TRAIN_GROUP(a.rec, acc, 4, a.rec + 8 * CHUNK_FLOATS)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[T][0][r] = a.dt * sigmoidf_(g[T][0][r]);
-        if (live) row_store(st + SV_A2 * plane, g);
-        lem_train_acc_init<NS>(a, 2, lane, hh, x, acc);               // g3 -> c, z'
-        LEM_TRAIN_GROUP(a.rec, y, acc, 4, a.rec + 8 * CHUNK_FLOATS)
+        for (int r = 0; r < 16; ++r) {
+            acc[r] = tanhf_(acc[r]);
+            z[r] = (1.0f - g[r]) * z[r] + g[r] * acc[r];
+        }
+        if (live) { tile_store(st + SV_C * plane, ct, acc); tile_store(st + SV_Z * plane, ct, z); }
+        tile_init<NS>(a, 0, ct, lane, hh, x, g);                      // g1 -> a1
+        LEM_TRAIN_GROUP(a.rec, g, 8, a.rec + 12 * CHUNK_FLOATS)
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
+        for (int r = 0; r < 16; ++r) g[r] = a.dt * sigmoidf_(g[r]);
+        if (live) tile_store(st + SV_A1 * plane, ct, g);
+        publish_tile(xs, ct, c, hh, z);                               // every wave is past the barrier after its last read of y
+        __syncthreads();
+        tile_init<NS>(a, 3, ct, lane, hh, x, acc);                    // lin -> d, y'        (xs = z')
+        LEM_TRAIN_GROUP(a.rec, acc, 12, a.rec)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[T][0][r] = tanhf_(acc[T][0][r]);
-                z[T][0][r] = (1.0f - g[T][0][r]) * z[T][0][r] + g[T][0][r] * acc[T][0][r];
-            }
-        if (live) { row_store(st + SV_C * plane, acc); row_store(st + SV_Z * plane, z); }
-        lem_train_acc_init<NS>(a, 0, lane, hh, x, g);                 // g1 -> a1
-        LEM_TRAIN_GROUP(a.rec, y, g, 8, a.rec + 12 * CHUNK_FLOATS)
-#pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[T][0][r] = a.dt * sigmoidf_(g[T][0][r]);
-        if (live) row_store(st + SV_A1 * plane, g);
-        lem_train_acc_init<NS>(a, 3, lane, hh, x, acc);               // lin -> d, y'
-        LEM_TRAIN_GROUP(a.rec, z, acc, 12, a.rec)
-#pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[T][0][r] = tanhf_(acc[T][0][r]);
-                y[T][0][r] = (1.0f - g[T][0][r]) * y[T][0][r] + g[T][0][r] * acc[T][0][r];
-            }
-        if (live) { row_store(st + SV_D * plane, acc); row_store(st + SV_Y * plane, y); }
+        for (int r = 0; r < 16; ++r) {
+            acc[r] = tanhf_(acc[r]);
+            y[r] = (1.0f - g[r]) * y[r] + g[r] * acc[r];
+        }
+        if (live) { tile_store(st + SV_D * plane, ct, acc); tile_store(st + SV_Y * plane, ct, y); }
+        publish_tile(xs, ct, c, hh, y);
+        __syncthreads();
     }
-    if (live) row_store(a.out + (size_t)n * H + 4 * hh, y);
+    if (live) tile_store(a.out + (size_t)n * H + 4 * hh, ct, y);
 }
 
 struct LemBwdArgs {
@@ -175,9 +185,10 @@ struct LemBwdArgs {
 
 __global__ __launch_bounds__(256) void lem_bptt_kernel(LemBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float xs[H * XS];
+    const int tid = threadIdx.x, lane = tid & 63, ct = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
-    const long n = (long)blockIdx.x * 128 + wave * 32 + c;
+    const long n = (long)blockIdx.x * 32 + c;
     const bool live = n < a.n_nodes;
     const long nc = live ? n : a.n_nodes - 1;
     const size_t plane = (size_t)a.n_nodes * a.t_len * H;
@@ -185,13 +196,10 @@ __global__ __launch_bounds__(256) void lem_bptt_kernel(LemBwdArgs a) {
     float* grow = a.dg + (size_t)nc * a.t_len * (4 * H) + 4 * hh;
     const float inv_dt = 1.0f / a.dt;
 
-    f32x16 dy[4][1], dz[4][1], p[4][1], q[4][1];
+    f32x16 dy, dz, p, q;
+    tile_load(a.gout + (size_t)nc * H + 4 * hh, ct, dy);
 #pragma unroll
-    for (int T = 0; T < 4; ++T) {
-        tile_load(a.gout + (size_t)nc * H + 4 * hh, T, dy[T][0]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dz[T][0][r] = 0.f;
-    }
+    for (int r = 0; r < 16; ++r) dz[r] = 0.f;
 
     WStage ws;
     wstage_load(ws, a.rec_t, tid);
@@ -201,52 +209,54 @@ __global__ __launch_bounds__(256) void lem_bptt_kernel(LemBwdArgs a) {
     for (int t = a.t_len - 1; t >= 0; --t) {
         const float* st = srow + (size_t)t * H;
         float* gt = grow + (size_t)t * (4 * H);
-        // y' = (1-a1) y + a1 d:  p = dg1, q = dl
-#pragma unroll
-        for (int T = 0; T < 4; ++T) {
+        {   // y' = (1-a1) y + a1 d:  p = dg1, q = dl
             f32x16 a1, d, yp;
-            tile_load(st + SV_A1 * plane, T, a1);
-            tile_load(st + SV_D * plane, T, d);
-            if (t > 0) tile_load(st - H + SV_Y * plane, T, yp);
+            tile_load(st + SV_A1 * plane, ct, a1);
+            tile_load(st + SV_D * plane, ct, d);
+            if (t > 0) tile_load(st - H + SV_Y * plane, ct, yp);
             else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) yp[r] = 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float g = dy[T][0][r];
-                const float da1 = g * (d[r] - yp[r]);
-                q[T][0][r] = g * a1[r] * (1.0f - d[r] * d[r]);
-                p[T][0][r] = da1 * a1[r] * (1.0f - a1[r] * inv_dt);
-                dy[T][0][r] = g * (1.0f - a1[r]);
+                const float g = dy[r];
+                q[r] = g * a1[r] * (1.0f - d[r] * d[r]);
+                p[r] = g * (d[r] - yp[r]) * a1[r] * (1.0f - a1[r] * inv_dt);
+                dy[r] = g * (1.0f - a1[r]);
             }
-            if (live) { tile_store(gt, T, p[T][0]); tile_store(gt + 3 * H, T, q[T][0]); }
+            if (live) { tile_store(gt, ct, p); tile_store(gt + 3 * H, ct, q); }
         }
-        LEM_TRAIN_GROUP(a.rec_t, p, dy, 0, a.rec_t + 4 * CHUNK_FLOATS)
-        LEM_TRAIN_GROUP(a.rec_t, q, dz, 4, a.rec_t + 8 * CHUNK_FLOATS)
-        // z' = (1-a2) z + a2 c:  p = dg2, q = dg3
-#pragma unroll
-        for (int T = 0; T < 4; ++T) {
+        publish_tile(xs, ct, c, hh, p);               // xs is free: the previous group ended with a barrier
+        __syncthreads();
+        LEM_TRAIN_GROUP(a.rec_t, dy, 0, a.rec_t + 4 * CHUNK_FLOATS)
+        publish_tile(xs, ct, c, hh, q);
+        __syncthreads();
+        LEM_TRAIN_GROUP(a.rec_t, dz, 4, a.rec_t + 8 * CHUNK_FLOATS)
+        {   // z' = (1-a2) z + a2 c:  p = dg2, q = dg3
             f32x16 a2, cc, zp;
-            tile_load(st + SV_A2 * plane, T, a2);
-            tile_load(st + SV_C * plane, T, cc);
-            if (t > 0) tile_load(st - H + SV_Z * plane, T, zp);
+            tile_load(st + SV_A2 * plane, ct, a2);
+            tile_load(st + SV_C * plane, ct, cc);
+            if (t > 0) tile_load(st - H + SV_Z * plane, ct, zp);
             else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zp[r] = 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float g = dz[T][0][r];
-                const float da2 = g * (cc[r] - zp[r]);
-                q[T][0][r] = g * a2[r] * (1.0f - cc[r] * cc[r]);
-                p[T][0][r] = da2 * a2[r] * (1.0f - a2[r] * inv_dt);
-                dz[T][0][r] = g * (1.0f - a2[r]);
+                const float g = dz[r];
+                q[r] = g * a2[r] * (1.0f - cc[r] * cc[r]);
+                p[r] = g * (cc[r] - zp[r]) * a2[r] * (1.0f - a2[r] * inv_dt);
+                dz[r] = g * (1.0f - a2[r]);
             }
-            if (live) { tile_store(gt + H, T, p[T][0]); tile_store(gt + 2 * H, T, q[T][0]); }
+            if (live) { tile_store(gt + H, ct, p); tile_store(gt + 2 * H, ct, q); }
         }
-        LEM_TRAIN_GROUP(a.rec_t, p, dy, 8, a.rec_t + 12 * CHUNK_FLOATS)
-        LEM_TRAIN_GROUP(a.rec_t, q, dy, 12, a.rec_t)
+        publish_tile(xs, ct, c, hh, p);
+        __syncthreads();
+        LEM_TRAIN_GROUP(a.rec_t, dy, 8, a.rec_t + 12 * CHUNK_FLOATS)
+        publish_tile(xs, ct, c, hh, q);
+        __syncthreads();
+        LEM_TRAIN_GROUP(a.rec_t, dy, 12, a.rec_t)
     }
 }
 #undef LEM_TRAIN_GROUP
@@ -292,7 +302,7 @@ extern "C" int msmp_lem_train_fwd_f32(const float* xin, int64_t n_nodes, int t_l
     MSMP_REQUIRE(ninp >= 1 && ninp <= LEM_MAX_INP, MSMP_ERR_UNSUPPORTED, "msmp_lem_train_fwd_f32: ninp=%d not in 1..%d", ninp, LEM_MAX_INP);
     const LemLayout L = lem_layout();
     LemTrainArgs a{xin, (long)n_nodes, t_len, dt, packed + L.rec, packed + L.bias, packed + L.wx, saved, y_out};
-    const unsigned grid = (unsigned)((n_nodes + 127) / 128);
+    const unsigned grid = (unsigned)((n_nodes + 31) / 32);
     hipStream_t st = (hipStream_t)stream;
     switch ((ninp + 1) / 2) {
         case 1: hipLaunchKernelGGL(lem_train_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a); break;
@@ -308,7 +318,7 @@ extern "C" int msmp_lem_train_bwd_f32(const float* grad_y, const float* saved, i
     MSMP_REQUIRE(grad_y && saved && packed_bwd && dg_out, MSMP_ERR_ARG, "msmp_lem_train_bwd_f32: null pointer");
     MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31) && t_len >= 1 && dt != 0.f, MSMP_ERR_ARG, "msmp_lem_train_bwd_f32: bad sizes");
     LemBwdArgs a{grad_y, saved, (long)n_nodes, t_len, dt, packed_bwd, dg_out};
-    const unsigned grid = (unsigned)((n_nodes + 127) / 128);
+    const unsigned grid = (unsigned)((n_nodes + 31) / 32);
     hipLaunchKernelGGL(lem_bptt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("lem_bptt_kernel");
 }
