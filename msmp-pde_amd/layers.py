@@ -59,19 +59,23 @@ class _MPLayerBase(nn.Module):
         self._make_update_net_2(hidden_features, out_features)
         self._packed = None
         self._packed_key = None
+        self._ps = None
 
     def _params8(self):
-        return (self.message_net_1[0].weight, self.message_net_1[0].bias, self.message_net_2[0].weight,
-                self.message_net_2[0].bias, self.update_net_1[0].weight, self.update_net_1[0].bias,
-                self.update_net_2[0].weight, self.update_net_2[0].bias)
+        ps = self._ps
+        if ps is None or ps[0] is not self.message_net_1[0].weight:      # (re-)collected when a Parameter object was replaced
+            ps = self._ps = (self.message_net_1[0].weight, self.message_net_1[0].bias, self.message_net_2[0].weight,
+                             self.message_net_2[0].bias, self.update_net_1[0].weight, self.update_net_1[0].bias,
+                             self.update_net_2[0].weight, self.update_net_2[0].bias)
+        return ps
 
     def packed(self):
         """Kernel-layout weight blob (msmp_pack_layer_f32), re-packed only when a parameter changed."""
         ps = self._params8()
-        key = tuple((p.data_ptr(), p._version, str(p.device), p.dtype) for p in ps)
+        key = (ps[0].data_ptr(), ps[7].data_ptr(), ps[0].dtype) + tuple(p._version for p in ps)
         if key != self._packed_key:
             dev = ps[0].device
-            if dev.type != 'cuda':
+            if dev.type != 'cuda' or any(p.device != dev for p in ps):
                 raise _lib.MsmpError('layer parameters must be on the GPU (HIP path only, no CPU fallback)')
             L = lib()
             n = L.msmp_packed_layer_floats(self.time_window, self.n_variables)
@@ -140,7 +144,7 @@ def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense
     gs = structure
     if gs is None or h.device.type != 'cuda':
         raise _lib.MsmpError('mp_layer needs CUDA tensors and a GraphStructure (HIP path only, no CPU fallback)')
-    need_grad = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in main.parameters()))
+    need_grad = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in main._params8()))
     hd, u, pos_x, variables = _f32c(h), _f32c(u), _f32c(pos_x).reshape(-1), _f32c(variables)
     n = hd.shape[0]
     assert n == gs.n_nodes and hd.shape[1] == HIDDEN and u.shape[1] == main.time_window
