@@ -600,3 +600,14 @@ def test_lem_encoder_in_kernel_input_assembly(mp, two_d, nv, tw, n):
             assert lem.encode_nodes(u, pos_x, pos_t, variables, dt, two_d, mlp) is None      # only the default edition has it
         finally:
             mp.lib().msmp_tune(b'lem', 3)
+
+
+def test_guard_bands_are_active(mp):
+    """The conftest fixture really wraps the allocations the host layer makes (torch.empty / empty_like on the GPU) in
+    sentinel bands: a kernel output sits 256 elements into a larger buffer whose margins are checked after each test."""
+    from msmp_pde_amd.layers import _mp_layer_hip       # noqa: F401  (the product allocates with torch.empty_like / empty)
+    t = torch.empty(1000, dtype=torch.float32, device='cuda')
+    assert t.storage_offset() == 256 and t._base is not None and t._base.numel() == 1000 + 512
+    assert abs(float(t._base[0]) - 12345.678) < 1e-2 and abs(float(t._base[-1]) - 12345.678) < 1e-2
+    u = torch.empty_like(t)
+    assert u.storage_offset() == 256 and u.data_ptr() % 256 == 0
