@@ -8,6 +8,7 @@ Reference classes:
   MP_PDE_Solver2D             experiments/models_gnn2D.py:17-141
   MP_PDE_Solver2DGated        experiments/models_gnn2D.py:143-288
   MP_PDE_Solver2DLEMLinGated  experiments/models_gnn2D.py:290-458      ("MSMP-PDE2D", train.py:116-120)
+  MP_PDE_SolverLEMLin / MP_PDE_Solver2DLEMLin   models_gnn.py:619-756 / models_gnn2D.py:920-1057   ("LEM" / "LEM2D" ablations)
 Encoder (embedding MLP / LEM), `double_mlp` and the decoder CNN stay in PyTorch-ROCm (BASELINE.json
 north_star); the L x [message -> mean -> update -> InstanceNorm (-> gate blend)] loop is
 msmp_mp_layer_f32.  `pde.L`, `pde.tmax`, `pde.dt` are read at call time (they are mutated after
@@ -237,6 +238,11 @@ class MP_PDE_SolverLEMLinGated(_SolverBase):
     GATED, LEM_ENCODER, LAYER = True, True, GNN_LayerLin
 
 
+class MP_PDE_SolverLEMLin(_SolverBase):
+    """experiments/models_gnn.py:619-756: LEM encoder in front of the plain GNN_Layer stack (no gate; train.py name 'LEM')."""
+    LEM_ENCODER = True
+
+
 class MP_PDE_Solver2D(_SolverBase):
     TWO_D = True
 
@@ -249,7 +255,13 @@ class MP_PDE_Solver2DLEMLinGated(_SolverBase):
     TWO_D, GATED, LEM_ENCODER, LAYER = True, True, True, GNN_LayerLin
 
 
+class MP_PDE_Solver2DLEMLin(_SolverBase):
+    """experiments/models_gnn2D.py:920-1057 (train.py name 'LEM2D')."""
+    TWO_D, LEM_ENCODER = True, True
+
+
 MODEL_NAMES = {   # experiments/train.py:34-183 getModel names -> class
     'MP-PDE': MP_PDE_Solver, 'Gated': MP_PDE_SolverGated, 'MSMP-PDE': MP_PDE_SolverLEMLinGated,
     'MP-PDE2D': MP_PDE_Solver2D, 'Gated2D': MP_PDE_Solver2DGated, 'MSMP-PDE2D': MP_PDE_Solver2DLEMLinGated,
+    'LEM': MP_PDE_SolverLEMLin, 'LEM2D': MP_PDE_Solver2DLEMLin,
 }

@@ -148,8 +148,8 @@ def lem_forward(inputs, weights, weights_lin_z, bias, bias_lin_z, dt=1.0):
 # --------------------------------------------------------------------------------------------
 # solver forward passes
 # --------------------------------------------------------------------------------------------
-KINDS_1D = ('MP_PDE_Solver', 'MP_PDE_SolverGated', 'MP_PDE_SolverLEMLinGated')
-KINDS_2D = ('MP_PDE_Solver2D', 'MP_PDE_Solver2DGated', 'MP_PDE_Solver2DLEMLinGated')
+KINDS_1D = ('MP_PDE_Solver', 'MP_PDE_SolverGated', 'MP_PDE_SolverLEMLinGated', 'MP_PDE_SolverLEMLin')
+KINDS_2D = ('MP_PDE_Solver2D', 'MP_PDE_Solver2DGated', 'MP_PDE_Solver2DLEMLinGated', 'MP_PDE_Solver2DLEMLin')
 
 _DECODER = {  # time_window -> (k1, stride1, k2); experiments/models_gnn.py:210-224, models_gnn2D.py:79-88
     20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}
@@ -182,13 +182,15 @@ def build_variables(kind, data, pde, eq_variables):
 
 def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=6, dtype=np.float64,
                    parts=False):
-    """forward(data) of the six in-scope solver classes.
+    """forward(data) of the in-scope solver classes.
     MP_PDE_Solver               experiments/models_gnn.py:229-281
     MP_PDE_SolverGated          experiments/models_gnn.py:1162-1218
     MP_PDE_SolverLEMLinGated    experiments/models_gnn.py:1315-1377
     MP_PDE_Solver2D             experiments/models_gnn2D.py:93-141
     MP_PDE_Solver2DGated        experiments/models_gnn2D.py:238-288
     MP_PDE_Solver2DLEMLinGated  experiments/models_gnn2D.py:396-458
+    MP_PDE_SolverLEMLin         experiments/models_gnn.py:696-756    (LEM encoder + plain GNN_Layer stack; train.py 'LEM')
+    MP_PDE_Solver2DLEMLin       experiments/models_gnn2D.py:1003-1057 (same, 2-D; train.py 'LEM2D')
     `sd` maps the reference's state_dict key names to arrays.  Row S1."""
     sd = {k: np.asarray(v, dtype=dtype) for k, v in sd.items()}
     tw = time_window
