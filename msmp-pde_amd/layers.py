@@ -139,8 +139,8 @@ def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense
     """One message-passing layer (or one gated pair) on the device through msmp_mp_layer_f32.
     h [N,128], u [N,Tw], pos_x [N,1] or [N], variables [N,nv]: float32 CUDA tensors.
     dense_message: None -> module default (factorised message_net_1); True -> literal per-edge GEMM.
-    Under autograd (training) the forward is the same HIP call and the backward is a PyTorch-ROCm recompute
-    (msmp_pde_amd.autograd; dedicated backward kernels are a later row)."""
+    Under autograd (training) the forward is the same HIP call and the backward an explicit recompute with library GEMMs
+    and the HIP glue / weight-gradient kernels of train_kernels.hip (msmp_pde_amd.autograd)."""
     gs = structure
     if gs is None or h.device.type != 'cuda':
         raise _lib.MsmpError('mp_layer needs CUDA tensors and a GraphStructure (HIP path only, no CPU fallback)')

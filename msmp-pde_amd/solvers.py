@@ -9,11 +9,13 @@ Reference classes:
   MP_PDE_Solver2DGated        experiments/models_gnn2D.py:143-288
   MP_PDE_Solver2DLEMLinGated  experiments/models_gnn2D.py:290-458      ("MSMP-PDE2D", train.py:116-120)
   MP_PDE_SolverLEMLin / MP_PDE_Solver2DLEMLin   models_gnn.py:619-756 / models_gnn2D.py:920-1057   ("LEM" / "LEM2D" ablations)
-Encoder (embedding MLP / LEM), `double_mlp` and the decoder CNN stay in PyTorch-ROCm (BASELINE.json
-north_star); the L x [message -> mean -> update -> InstanceNorm (-> gate blend)] loop is
-msmp_mp_layer_f32.  `pde.L`, `pde.tmax`, `pde.dt` are read at call time (they are mutated after
-construction, experiments/train.py:355-358).  Compute dtype is float32; the result is returned in
-the dtype of `data.x`.
+Inference (no autograd) runs on HIP kernels end to end: the encoder (msmp_lem_encoder_nodes_f32 with lemoutput_mlp fused, or
+msmp_mlp2_swish_f32 for embedding_mlp), the L x [message -> mean -> update -> InstanceNorm (-> gate blend)] loop
+(msmp_mp_layer_f32) and the decoder CNN with the Euler update (msmp_decoder_f32 / msmp_decoder2d_f32); only `double_mlp` of
+the 2-D classes and a few feature-preparation ops are PyTorch-ROCm.  Under autograd the layers and the LEM encoder use their
+HIP forward / backward pairs (autograd.py, lem.py) and the small encoder / decoder modules PyTorch-ROCm ops.  `pde.L`,
+`pde.tmax`, `pde.dt` are read at call time (they are mutated after construction, experiments/train.py:355-358).  Compute
+dtype is float32; the result is returned in the dtype of `data.x`.
 """
 import torch
 from torch import nn
