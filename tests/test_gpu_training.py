@@ -233,3 +233,31 @@ def test_explicit_backward_equals_autograd_recompute(mp):
         for k in grads[0]:
             err = (grads[0][k] - grads[1][k]).abs().max().item()
             assert err < 1e-4 * grads[1][k].abs().max().item() + 1e-5 * scale, (name, k, err)
+
+
+def test_grad_weights_kernel_shapes_and_strides(mp):
+    """msmp_grad_weights_f32 through autograd.grad_weights: dW = A^T B and db = column sums for 8 pairs in one call, row
+    counts that are no multiple of the 8-row step / 128-row split (1 ... 70 001), k2 from 1 to the maximum 319, row-strided
+    views for both operands; against float64.  Also: repeatable bit for bit (fixed-order reduction) and the size limit."""
+    from msmp_pde_amd.autograd import grad_weights
+    g = torch.Generator(device='cpu').manual_seed(9)
+    shapes = [(1, 1), (7, 128), (129, 136), (1000, 159), (1601, 160), (9408, 284), (70001, 311), (300, 319)]
+    pairs, refs = [], []
+    for i, (rows, k2) in enumerate(shapes):
+        a_full = torch.randn(rows, 512, generator=g).cuda()
+        b_full = torch.randn(rows, k2 + 5, generator=g).cuda()
+        a = a_full[:, 128:256] if i % 2 else a_full[:, :128].contiguous()       # lda = 512 or 128
+        b = b_full[:, :k2]                                                      # ldb = k2 + 5
+        pairs.append((a, b))
+        refs.append((a.double().t() @ b.double(), a.double().sum(0)))
+    out = grad_weights(pairs)
+    for i, (rw, rb) in enumerate(refs):
+        dw, db = out[2 * i], out[2 * i + 1]
+        assert dw.shape == rw.shape and db.shape == rb.shape
+        tol = 2e-6 * (shapes[i][0] ** 0.5 + 4)                                  # fp32 sums of `rows` O(1) terms
+        assert (dw.double() - rw).abs().max().item() < tol * 4, (shapes[i], (dw.double() - rw).abs().max().item())
+        assert (db.double() - rb).abs().max().item() < tol * 4
+    again = grad_weights(pairs)
+    assert all(torch.equal(x, y) for x, y in zip(out, again))
+    with pytest.raises(ValueError):
+        grad_weights([(pairs[0][0], torch.randn(1, 320).cuda())])              # k2 > 319
