@@ -56,7 +56,7 @@ class GraphStructure(object):
         self.graph_ptr = torch.zeros(self.n_graphs + 1, dtype=torch.int32, device=dev)
         self.graph_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
         self.max_graph_nodes = int(counts.max().item()) if counts.numel() else 0
-        self._tgt_long = self._col_long = None
+        self._tgt_long = self._col_long = self._by_source = None
         self.rowptr = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
         self.col = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
         self.tgt = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
@@ -80,6 +80,17 @@ class GraphStructure(object):
     def col_long(self):
         self.tgt_long
         return self._col_long
+
+    def by_source(self):
+        """(perm, rowptr): the edges regrouped by SOURCE node (stable), for means over a node's out-edges
+        (msmp_scatter_mean_f32 on msg[perm]); made once."""
+        if self._by_source is None:
+            src = self.col_long
+            perm = torch.sort(src, stable=True)[1]
+            rowptr = torch.zeros(self.n_nodes + 1, dtype=torch.int32, device=src.device)
+            rowptr[1:] = torch.cumsum(torch.bincount(src, minlength=self.n_nodes), 0).to(torch.int32)
+            self._by_source = (perm, rowptr)
+        return self._by_source
 
     def matches(self, edge_index, batch):
         return self._key == (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,

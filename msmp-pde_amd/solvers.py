@@ -43,10 +43,32 @@ def _decoder_autograd(x, conv1, conv2):
     return torch.einsum('nctk,ock->not', w2, conv2.weight) + conv2.bias[None, :, None]
 
 
+class _OutEdgeMean(torch.autograd.Function):
+    """Mean of a per-edge tensor [E,128] over each node's OUT-edges (torch_scatter `scatter(..., edge_index[0], reduce='mean')`,
+    models_gnn2D.py:607-608) in a fixed summation order: edges regrouped by source once per graph structure, then
+    msmp_scatter_mean_f32.  Nodes without out-edges get 0."""
+
+    @staticmethod
+    def forward(ctx, msg, gs):
+        perm, rowptr = gs.by_source()
+        m = msg.detach().to(torch.float32)[perm].contiguous()
+        out = torch.empty(gs.n_nodes, m.shape[1], dtype=torch.float32, device=m.device)
+        check(lib().msmp_scatter_mean_f32(ptr(m), ptr(rowptr), gs.n_nodes, ptr(out), current_stream()), 'msmp_scatter_mean_f32')
+        ctx.gs = gs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        perm, rowptr = ctx.gs.by_source()
+        deg = (rowptr[1:] - rowptr[:-1]).clamp(min=1).to(g.dtype)
+        return (g / deg[:, None])[ctx.gs.col_long], None
+
+
 class _SolverBase(nn.Module):
     TWO_D = False
     GATED = False
     LEM_ENCODER = False
+    G2 = False
     LAYER = GNN_Layer
 
     def __init__(self, pde, time_window=25, hidden_features=128, hidden_layer=6, eq_variables={}, save_state=None):
@@ -66,7 +88,7 @@ class _SolverBase(nn.Module):
         mk = lambda: self.LAYER(in_features=hidden_features, hidden_features=hidden_features,
                                 out_features=hidden_features, time_window=comps * time_window, n_variables=nv)
         self.gnn_layers = nn.ModuleList(mk() for _ in range(hidden_layer))
-        if self.GATED:
+        if self.GATED or self.G2:
             self.gnn_layers_gate = nn.ModuleList(mk() for _ in range(hidden_layer))
             self.swish = Swish()
         if self.LEM_ENCODER:
@@ -132,6 +154,14 @@ class _SolverBase(nn.Module):
             return self.lemoutput_mlp(h)
         return self.embedding_lem.encode(lem_in, self.lemoutput_mlp)       # fused HIP kernel (recurrence + MLP)
 
+    def _g2_pair(self, h, u, pos_x, variables, gs, i):
+        """models_gnn2D.py:606-611 (gradient gating): tau = tanh(mean over the out-edges j -> i of node j of |t_j - t_i|^2) with
+        t = Swish(gate layer), then the same blend as the gated classes.  Both layers are the fused HIP layer call
+        (GNN_LayerLin incl. its InstanceNorm); the gate statistic and the blend are PyTorch-ROCm ops."""
+        t = self.swish(mp_layer(h, u, pos_x, variables, gs, self.gnn_layers_gate[i], None))
+        tau = torch.tanh(_OutEdgeMean.apply((t[gs.col_long] - t[gs.tgt_long]) ** 2, gs))
+        return (1.0 - tau) * h + tau * self.swish(mp_layer(h, u, pos_x, variables, gs, self.gnn_layers[i], None))
+
     def _embed_hip(self, u, pos_x, variables):
         """embedding_mlp as one HIP kernel (msmp_mlp2_swish_f32); the packed weights are cached per parameter version."""
         lin1, lin2 = self.embedding_mlp[0], self.embedding_mlp[2]
@@ -167,6 +197,9 @@ class _SolverBase(nn.Module):
 
         h = self._encode(u, pos_x, pos_t, variables, dt)
         for i in range(self.hidden_layer):
+            if self.G2:
+                h = self._g2_pair(h, u, pos_x, variables, gs, i)
+                continue
             gate = self.gnn_layers_gate[i] if self.GATED else None
             h = mp_layer(h, u, pos_x, variables, gs, self.gnn_layers[i], gate)
 
@@ -262,8 +295,13 @@ class MP_PDE_Solver2DLEMLin(_SolverBase):
     TWO_D, LEM_ENCODER = True, True
 
 
+class MP_PDE_Solver2DLEMLinG2(_SolverBase):
+    """experiments/models_gnn2D.py:460-620 (train.py name 'MSG2-PDE2D'): the gated 2-D LEM model with gradient gating."""
+    TWO_D, LEM_ENCODER, G2, LAYER = True, True, True, GNN_LayerLin
+
+
 MODEL_NAMES = {   # experiments/train.py:34-183 getModel names -> class
     'MP-PDE': MP_PDE_Solver, 'Gated': MP_PDE_SolverGated, 'MSMP-PDE': MP_PDE_SolverLEMLinGated,
     'MP-PDE2D': MP_PDE_Solver2D, 'Gated2D': MP_PDE_Solver2DGated, 'MSMP-PDE2D': MP_PDE_Solver2DLEMLinGated,
-    'LEM': MP_PDE_SolverLEMLin, 'LEM2D': MP_PDE_Solver2DLEMLin,
+    'LEM': MP_PDE_SolverLEMLin, 'LEM2D': MP_PDE_Solver2DLEMLin, 'MSG2-PDE2D': MP_PDE_Solver2DLEMLinG2,
 }

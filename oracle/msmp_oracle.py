@@ -149,7 +149,8 @@ def lem_forward(inputs, weights, weights_lin_z, bias, bias_lin_z, dt=1.0):
 # solver forward passes
 # --------------------------------------------------------------------------------------------
 KINDS_1D = ('MP_PDE_Solver', 'MP_PDE_SolverGated', 'MP_PDE_SolverLEMLinGated', 'MP_PDE_SolverLEMLin')
-KINDS_2D = ('MP_PDE_Solver2D', 'MP_PDE_Solver2DGated', 'MP_PDE_Solver2DLEMLinGated', 'MP_PDE_Solver2DLEMLin')
+KINDS_2D = ('MP_PDE_Solver2D', 'MP_PDE_Solver2DGated', 'MP_PDE_Solver2DLEMLinGated', 'MP_PDE_Solver2DLEMLin',
+            'MP_PDE_Solver2DLEMLinG2')
 
 _DECODER = {  # time_window -> (k1, stride1, k2); experiments/models_gnn.py:210-224, models_gnn2D.py:79-88
     20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}
@@ -191,6 +192,7 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
     MP_PDE_Solver2DLEMLinGated  experiments/models_gnn2D.py:396-458
     MP_PDE_SolverLEMLin         experiments/models_gnn.py:696-756    (LEM encoder + plain GNN_Layer stack; train.py 'LEM')
     MP_PDE_Solver2DLEMLin       experiments/models_gnn2D.py:1003-1057 (same, 2-D; train.py 'LEM2D')
+    MP_PDE_Solver2DLEMLinG2     experiments/models_gnn2D.py:565-620   (gradient-gated blend; train.py 'MSG2-PDE2D')
     `sd` maps the reference's state_dict key names to arrays.  Row S1."""
     sd = {k: np.asarray(v, dtype=dtype) for k, v in sd.items()}
     tw = time_window
@@ -203,6 +205,7 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
     dt = np.cumsum(np.ones(tw, dtype=dtype) * pde.dt)
 
     gated = 'Gated' in kind
+    g2 = kind.endswith('G2')
     if 'LEM' in kind:
         if two_d:   # models_gnn2D.py:421-436
             ts = dt[None, :] + pos_t
@@ -223,7 +226,17 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
 
     hs = []
     for i in range(hidden_layer):
-        if gated:   # models_gnn.py:1204-1207 / 1365-1368; models_gnn2D.py:266-269 / 438-441.  Row L5.
+        if g2:      # models_gnn2D.py:606-611: tau = tanh(mean over the out-edges (j -> i) of j of |tau_j - tau_i|^2), tau = Swish(gate layer)
+            pg = layer_params(sd, f'gnn_layers_gate.{i}.')
+            pm = layer_params(sd, f'gnn_layers.{i}.')
+            tau = swish(mp_layer(pg, h, u, pos_x, variables, ei, batch, lin=True))
+            d2 = np.abs(tau[ei[0]] - tau[ei[1]]) ** 2
+            acc = np.zeros_like(tau)
+            np.add.at(acc, ei[0], d2)
+            cnt = np.bincount(ei[0], minlength=tau.shape[0]).astype(dtype)
+            tau = np.tanh(acc / np.maximum(cnt, 1.0)[:, None])        # torch_scatter mean: empty segments -> 0
+            h = (1.0 - tau) * h + tau * swish(mp_layer(pm, h, u, pos_x, variables, ei, batch, lin=True))
+        elif gated:   # models_gnn.py:1204-1207 / 1365-1368; models_gnn2D.py:266-269 / 438-441.  Row L5.
             pg = layer_params(sd, f'gnn_layers_gate.{i}.')
             pm = layer_params(sd, f'gnn_layers.{i}.')
             tau = sigmoid(mp_layer(pg, h, u, pos_x, variables, ei, batch, lin=True))

@@ -87,7 +87,13 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
         h = swish(F.linear(torch.cat((u, pos_x, variables), -1), sd['embedding_mlp.0.weight'], sd['embedding_mlp.0.bias']))
         h = swish(F.linear(h, sd['embedding_mlp.2.weight'], sd['embedding_mlp.2.bias']))
     for i in range(hidden_layer):
-        if 'Gated' in kind:
+        if kind.endswith('G2'):
+            tau = swish(mp_layer(sd, f'gnn_layers_gate.{i}.', h, u, pos_x, variables, ei, batch, b, True))
+            d2 = (tau[ei[0]] - tau[ei[1]]).abs() ** 2
+            cnt = torch.bincount(ei[0], minlength=tau.shape[0]).clamp(min=1).to(tau.dtype)
+            tau = torch.tanh(torch.zeros_like(tau).index_add_(0, ei[0], d2) / cnt[:, None])
+            h = (1.0 - tau) * h + tau * swish(mp_layer(sd, f'gnn_layers.{i}.', h, u, pos_x, variables, ei, batch, b, True))
+        elif 'Gated' in kind:
             tau = torch.sigmoid(mp_layer(sd, f'gnn_layers_gate.{i}.', h, u, pos_x, variables, ei, batch, b, True))
             h = (1.0 - tau) * h + tau * swish(mp_layer(sd, f'gnn_layers.{i}.', h, u, pos_x, variables, ei, batch, b, True))
         else:
