@@ -228,7 +228,8 @@ int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len, int ninp,
  * ------------------------------------------------------------------------------------------- */
 /* 1-D solver decoder, experiments/models_gnn.py:210-224 (output_mlp for time_window 20 / 25 / 50) and
  * :275-279:  out = u[:, -1:] + cumsum(dt) * Conv1d(8,1,k2)(Swish(Conv1d(1,8,k1,stride)(h[:, None, :]))).
- * w1 [8,1,k1], b1 [8], w2 [1,8,k2], b2 [1] in the reference's Conv1d layouts; h [N,128]; u, out [N,tw]. */
+ * w1 [8,1,k1], b1 [8], w2 [1,8,k2], b2 [1] in the reference's Conv1d layouts; h [N,128]; u, out [N,tw].
+ * u == NULL: out = the decoder output alone (no Euler update), what MSSMP_PDE_Solver_sub returns (:1679-1682). */
 int msmp_decoder_f32(const float* h, const float* u, int64_t n_nodes, int tw, const float* w1,
                      const float* b1, const float* w2, const float* b2, float dt, float* out,
                      msmp_stream_t stream);

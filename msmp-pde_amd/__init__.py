@@ -10,5 +10,5 @@ from .layers import Swish, GNN_Layer, GNN_LayerLin, mp_layer                  # 
 from .lem import LEM                                                          # noqa: F401
 from .solvers import (MP_PDE_Solver, MP_PDE_SolverGated, MP_PDE_SolverLEMLinGated, MP_PDE_Solver2D,   # noqa: F401
                       MP_PDE_Solver2DGated, MP_PDE_Solver2DLEMLinGated, MP_PDE_SolverLEMLin, MP_PDE_Solver2DLEMLin,
-                      MP_PDE_Solver2DLEMLinG2,
+                      MP_PDE_Solver2DLEMLinG2, MSSMP_PDE_Solver, MSSMP_PDE_Solver_sub,
                       MODEL_NAMES)

@@ -63,8 +63,13 @@ __global__ __launch_bounds__(256) void decoder_kernel(DecArgs a) {
             o[t] = s;
         }
     }
-    const float ul = a.u[(size_t)n * TW + TW - 1];
     float* op = a.out + (size_t)n * TW;
+    if (a.u == nullptr) {                   // the decoder output alone (MSSMP_PDE_Solver_sub, models_gnn.py:1679-1682)
+#pragma unroll
+        for (int t = 0; t < TW; ++t) op[t] = o[t];
+        return;
+    }
+    const float ul = a.u[(size_t)n * TW + TW - 1];
     float tcum = 0.f;
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
@@ -189,7 +194,7 @@ extern "C" int msmp_decoder2d_f32(const float* hd, const float* u, int64_t n_nod
 
 extern "C" int msmp_decoder_f32(const float* h, const float* u, int64_t n_nodes, int tw, const float* w1, const float* b1,
                                 const float* w2, const float* b2, float dt, float* out, msmp_stream_t stream) {
-    MSMP_REQUIRE(h && u && w1 && b1 && w2 && b2 && out, MSMP_ERR_ARG, "msmp_decoder_f32: null pointer");
+    MSMP_REQUIRE(h && w1 && b1 && w2 && b2 && out, MSMP_ERR_ARG, "msmp_decoder_f32: null pointer");
     MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31), MSMP_ERR_ARG, "msmp_decoder_f32: bad n_nodes");
     DecArgs a{h, u, (long)n_nodes, w1, b1, w2, b2, dt, out};
     const unsigned grid = (unsigned)((n_nodes + 255) / 256);

@@ -69,6 +69,7 @@ class _SolverBase(nn.Module):
     GATED = False
     LEM_ENCODER = False
     G2 = False
+    RETURN_DIFF = False     # MSSMP_PDE_Solver_sub: forward returns the decoder output, not the Euler update
     LAYER = GNN_Layer
 
     def __init__(self, pde, time_window=25, hidden_features=128, hidden_layer=6, eq_variables={}, save_state=None):
@@ -216,14 +217,14 @@ class _SolverBase(nn.Module):
                                            float(self.pde.dt), ptr(out), current_stream()), 'msmp_decoder2d_f32')
         elif grad_path:
             diff = _decoder_autograd(h[:, None], self.output_mlp[0], self.output_mlp[2]).squeeze(1)   # differentiable decoder
-            out = u[:, -1:] + dt.view(1, tw) * diff
+            out = diff if self.RETURN_DIFF else u[:, -1:] + dt.view(1, tw) * diff
         else:                           # models_gnn.py:275-279, fused: conv -> Swish -> conv -> u + cumsum(dt) * diff
             out = torch.empty_like(u)
             c1, c2 = self.output_mlp[0], self.output_mlp[2]
             w = [p.detach().to(torch.float32).contiguous() for p in (c1.weight, c1.bias, c2.weight, c2.bias)]   # kept alive
             h = h.contiguous()
-            check(lib().msmp_decoder_f32(ptr(h), ptr(u), u.shape[0], tw, ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[3]),
-                                         float(self.pde.dt), ptr(out), current_stream()), 'msmp_decoder_f32')
+            check(lib().msmp_decoder_f32(ptr(h), None if self.RETURN_DIFF else ptr(u), u.shape[0], tw, ptr(w[0]), ptr(w[1]), ptr(w[2]),
+                                         ptr(w[3]), float(self.pde.dt), ptr(out), current_stream()), 'msmp_decoder_f32')
         return out.to(u_in.dtype)
 
 
@@ -300,8 +301,36 @@ class MP_PDE_Solver2DLEMLinG2(_SolverBase):
     TWO_D, LEM_ENCODER, G2, LAYER = True, True, True, GNN_LayerLin
 
 
+class MSSMP_PDE_Solver_sub(_SolverBase):
+    """experiments/models_gnn.py:1525-1682: the MSMP-PDE network whose forward returns the decoder output `diff`."""
+    GATED, LEM_ENCODER, RETURN_DIFF, LAYER = True, True, True, GNN_LayerLin
+
+
+class MSSMP_PDE_Solver(nn.Module):
+    """experiments/models_gnn.py:1684-1745 (train.py name 'MSSMP-PDE'): two MSMP-PDE networks, `diff` and `scale`;
+    out = (1 - scale) * u[:, -1] + cumsum(dt) * (scale * diff)."""
+
+    def __init__(self, pde, time_window=25, hidden_features=128, hidden_layer=6, eq_variables={}):
+        super().__init__()
+        self.pde, self.time_window, self.eq_variables = pde, time_window, eq_variables
+        self.out_features, self.hidden_features, self.hidden_layer = time_window, hidden_features, hidden_layer
+        self.diff = MSSMP_PDE_Solver_sub(pde, time_window, hidden_features, hidden_layer, eq_variables)
+        self.scale = MSSMP_PDE_Solver_sub(pde, time_window, hidden_features, hidden_layer, eq_variables)
+
+    def __repr__(self):
+        return 'GNN'
+
+    def forward(self, data):
+        scale = self.scale(data)
+        diff = self.diff(data)
+        u = data.x
+        dt = torch.cumsum(torch.ones(1, self.time_window, dtype=u.dtype, device=u.device) * self.pde.dt, 1)
+        return (1.0 - scale) * u[:, -1:] + dt * (scale * diff)
+
+
 MODEL_NAMES = {   # experiments/train.py:34-183 getModel names -> class
     'MP-PDE': MP_PDE_Solver, 'Gated': MP_PDE_SolverGated, 'MSMP-PDE': MP_PDE_SolverLEMLinGated,
     'MP-PDE2D': MP_PDE_Solver2D, 'Gated2D': MP_PDE_Solver2DGated, 'MSMP-PDE2D': MP_PDE_Solver2DLEMLinGated,
     'LEM': MP_PDE_SolverLEMLin, 'LEM2D': MP_PDE_Solver2DLEMLin, 'MSG2-PDE2D': MP_PDE_Solver2DLEMLinG2,
+    'MSSMP-PDE': MSSMP_PDE_Solver,
 }

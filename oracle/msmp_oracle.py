@@ -148,7 +148,7 @@ def lem_forward(inputs, weights, weights_lin_z, bias, bias_lin_z, dt=1.0):
 # --------------------------------------------------------------------------------------------
 # solver forward passes
 # --------------------------------------------------------------------------------------------
-KINDS_1D = ('MP_PDE_Solver', 'MP_PDE_SolverGated', 'MP_PDE_SolverLEMLinGated', 'MP_PDE_SolverLEMLin')
+KINDS_1D = ('MP_PDE_Solver', 'MP_PDE_SolverGated', 'MP_PDE_SolverLEMLinGated', 'MP_PDE_SolverLEMLin', 'MSSMP_PDE_Solver')
 KINDS_2D = ('MP_PDE_Solver2D', 'MP_PDE_Solver2DGated', 'MP_PDE_Solver2DLEMLinGated', 'MP_PDE_Solver2DLEMLin',
             'MP_PDE_Solver2DLEMLinG2')
 
@@ -182,7 +182,7 @@ def build_variables(kind, data, pde, eq_variables):
 
 
 def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=6, dtype=np.float64,
-                   parts=False):
+                   parts=False, decoder_diff=False):
     """forward(data) of the in-scope solver classes.
     MP_PDE_Solver               experiments/models_gnn.py:229-281
     MP_PDE_SolverGated          experiments/models_gnn.py:1162-1218
@@ -193,9 +193,18 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
     MP_PDE_SolverLEMLin         experiments/models_gnn.py:696-756    (LEM encoder + plain GNN_Layer stack; train.py 'LEM')
     MP_PDE_Solver2DLEMLin       experiments/models_gnn2D.py:1003-1057 (same, 2-D; train.py 'LEM2D')
     MP_PDE_Solver2DLEMLinG2     experiments/models_gnn2D.py:565-620   (gradient-gated blend; train.py 'MSG2-PDE2D')
+    MSSMP_PDE_Solver            experiments/models_gnn.py:1721-1745   (two MSMP-PDE networks `diff.*`, `scale.*`, each returning
+                                its decoder output (:1679-1682, decoder_diff=True); train.py 'MSSMP-PDE')
     `sd` maps the reference's state_dict key names to arrays.  Row S1."""
     sd = {k: np.asarray(v, dtype=dtype) for k, v in sd.items()}
     tw = time_window
+    if kind == 'MSSMP_PDE_Solver':
+        sub = lambda pre: solver_forward('MP_PDE_SolverLEMLinGated', {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)},
+                                         data, pde, time_window, eq_variables, hidden_layer, dtype, decoder_diff=True)
+        scale, diff = sub('scale.'), sub('diff.')
+        u = np.asarray(data.x, dtype=dtype)
+        dt = np.cumsum(np.ones(time_window, dtype=dtype) * pde.dt)
+        return (1.0 - scale) * u[:, -1:] + dt[None, :] * (scale * diff)
     two_d = kind in KINDS_2D
     u = np.asarray(data.x, dtype=dtype)
     ei = np.asarray(data.edge_index)
@@ -255,7 +264,7 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
     else:           # models_gnn.py:275-279
         diff = conv1d(swish(conv1d(h[:, None, :], sd['output_mlp.0.weight'], sd['output_mlp.0.bias'], s1)),
                       sd['output_mlp.2.weight'], sd['output_mlp.2.bias'], 1)[:, 0, :]
-        out = u[:, -1:] + dt[None, :] * diff
+        out = diff if decoder_diff else u[:, -1:] + dt[None, :] * diff
     if parts:
         return SimpleNamespace(out=out, h_enc=h_enc, hs=hs)
     return out

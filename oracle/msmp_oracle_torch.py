@@ -58,13 +58,20 @@ def lem_forward(inputs, w, wz, bias, bz, dt=1.0):
     return y
 
 
-def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=6, as_numpy=True):
+def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=6, as_numpy=True, decoder_diff=False):
     """forward(data) of the six in-scope solver classes (see msmp_oracle.solver_forward for the line map).
     `sd` values may be float64 torch tensors that require grad (as_numpy=False keeps the autograd graph:
     used to check the product's gradients)."""
     t64 = lambda a: a.to(torch.float64) if torch.is_tensor(a) else torch.as_tensor(a).to(torch.float64)
     sd = {k: t64(v) for k, v in sd.items()}
     tw = time_window
+    if kind == 'MSSMP_PDE_Solver':
+        sub = lambda pre: solver_forward('MP_PDE_SolverLEMLinGated', {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)},
+                                         data, pde, tw, eq_variables, hidden_layer, as_numpy=False, decoder_diff=True)
+        scale, diff = sub('scale.'), sub('diff.')
+        dt = torch.cumsum(torch.ones(tw, dtype=torch.float64) * pde.dt, 0)
+        out = (1.0 - scale) * t64(data.x)[:, -1:] + dt[None, :] * (scale * diff)
+        return out.detach().numpy() if as_numpy else out
     two_d = kind in O.KINDS_2D
     u = t64(data.x)
     ei = torch.as_tensor(data.edge_index).long()
@@ -107,5 +114,5 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
     else:
         diff = F.conv1d(swish(F.conv1d(h[:, None, :], sd['output_mlp.0.weight'], sd['output_mlp.0.bias'], stride=s1)),
                         sd['output_mlp.2.weight'], sd['output_mlp.2.bias'])[:, 0, :]
-        out = u[:, -1:] + dt[None, :] * diff
+        out = diff if decoder_diff else u[:, -1:] + dt[None, :] * diff
     return out.detach().numpy() if as_numpy else out
