@@ -102,8 +102,19 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = None
+
+
 def current_stream():
+    """Raw hipStream_t of torch's current stream on the current device (every launch is stream-ordered with torch's own work).
+    Goes through the C accessor: building a torch.cuda.Stream object per kernel launch costs ~10 us of host time, which is
+    what bounds small batches (the launches of a 32-graph rollout step, the backward of a 16-graph training batch)."""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', False)
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
