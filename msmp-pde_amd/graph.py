@@ -176,6 +176,29 @@ class GraphCreator(object):
         self.x_res = x_resolution
         self.device = device
         self._edge_cache = {}
+        self._small = {}      # device-resident index helpers (step lists, window offsets, the time axis), see _cached
+
+    def _cached(self, key, make):
+        """Small tensors that repeat from one rollout step to the next (the reference rebuilds them on the host every call):
+        keeping them on the device removes a handful of H2D copies and tiny kernels per step -- a 32-graph step is ~60
+        dependent launches, so each one counts there."""
+        v = self._small.get(key)
+        if v is None:
+            if len(self._small) > 256:
+                self._small.clear()
+            v = self._small[key] = make()
+        return v
+
+    def _steps_on(self, steps, device):
+        if torch.is_tensor(steps):
+            return steps.to(device=device, dtype=torch.long)
+        steps = tuple(int(s) for s in steps)
+        return self._cached(('steps', steps, str(device)), lambda: torch.tensor(steps, dtype=torch.long, device=device))
+
+    def _time_axis_on(self, device):
+        p = self.pde
+        return self._cached(('t', float(p.tmin), float(p.tmax), int(p.grid_size[0]), str(device)),
+                            lambda: torch_time_axis(p).to(device))
 
     def to(self, device):
         self.device = device
@@ -183,12 +206,12 @@ class GraphCreator(object):
 
     # -- common/utils.py:300-317
     def create_data(self, datapoints, steps):
-        steps_t = torch.as_tensor(steps, device=datapoints.device)
-        b = torch.arange(datapoints.shape[0], device=datapoints.device)[:, None]
-        win = torch.arange(self.tw, device=datapoints.device)[None, :]
-        data = datapoints[b, steps_t[:, None] - self.tw + win]
-        labels = datapoints[b, steps_t[:, None] + win]
-        return data, labels
+        dev, tw = datapoints.device, self.tw
+        steps_t = self._steps_on(steps, dev)
+        b = self._cached(('b', datapoints.shape[0], str(dev)), lambda: torch.arange(datapoints.shape[0], device=dev)[:, None])
+        win = self._cached(('win', tw, str(dev)), lambda: torch.arange(-tw, tw, device=dev)[None, :])
+        block = datapoints[b, steps_t[:, None] + win]         # one gather: [step - tw, step) is the data, [step, step + tw) the labels
+        return block[:, :tw], block[:, tw:]
 
     def _flatten(self, block):
         """[B,tw,nx] -> [B*nx, tw]; AD: [B,tw,2,nx] -> [B*nx, 2*tw] component-major (utils.py:350-357)."""
@@ -267,9 +290,11 @@ class GraphCreator(object):
         else:
             graph.x = torch.cat((graph.x, pred.to(graph.x.dtype)), 1)[:, keep:]
         nx = self.pde.grid_size[1]
-        t = torch_time_axis(self.pde)
-        steps_t = torch.as_tensor(steps, dtype=torch.long)
         device = graph.x.device
         graph.y = self._flatten(labels.to(device))
-        graph.pos[:, 0] = t[steps_t].to(device).repeat_interleave(nx).to(graph.pos.dtype)
+        t_now = self._time_axis_on(device)[self._steps_on(steps, device)]          # float64 values of the CPU linspace
+        if graph.pos.is_contiguous():
+            graph.pos.view(-1, nx, graph.pos.shape[1])[:, :, 0] = t_now[:, None].to(graph.pos.dtype)
+        else:
+            graph.pos[:, 0] = t_now.repeat_interleave(nx).to(graph.pos.dtype)
         return graph
