@@ -63,6 +63,8 @@ const char* msmp_last_error(void);
  *             one XCD (measured: no effect, the tiles share too little); 0 (default): tile b.
  *   "edge_ws" 1: persistent weight-stationary message + mean kernel (max in-degree <= 32); 0 (default): streamed weights.
  *   "tail"    1 (default): msmp_mp_layer_f32 uses msmp_node_tail_f32 for graphs of up to 128 nodes; 0: the piecewise kernels.
+ *   "pair"    gated pair: both heads' projection / message kernels in one launch each (bit-identical results): 0 never,
+ *             1 (default) for batches of up to 65 536 nodes, where a step is bound by the latency of its ~60 dependent launches, 2 always.
  *   "lem"     LEM encoder edition (3 weight-stationary, default; 1 / 2 streamed-weight split kernels; 0 fp32 MFMA). */
 int msmp_tune(const char* key, int value);
 

@@ -444,7 +444,8 @@ extern "C" int msmp_gate_blend_f32(const float* h, const float* gate_pre, const 
 }
 
 // Workspace of the chained layer: [msg [E,128] unless the fused edge kernel applies] | agg [N,128] |
-// pre_main [N,128] | pre_gate [N,128] | P [N,128] | Q [N,128]
+// pre_main [N,128] | pre_gate [N,128] | P [N,128] | Q [N,128] | Q' [N,128] (second head's Q when a gated pair is projected in one launch;
+// its P takes the pre_main slot, unused on that path)
 static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 static bool fused_ok(int max_in_degree) { return max_in_degree >= 0 && max_in_degree <= 256; }
 
@@ -452,7 +453,7 @@ extern "C" size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges
     const size_t msg = fused_ok(max_in_degree) ? 0 : align256((size_t)n_edges * H * sizeof(float));
     const size_t nod = align256((size_t)n_nodes * H * sizeof(float));
     (void)gated;
-    return msg + nod * 5 + 256;
+    return msg + nod * 6 + 256;
 }
 
 extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars,
@@ -495,8 +496,14 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
     };
     // node tail (rows L3-L5): one launch per layer when the graphs fit a workgroup (update head(s) + InstanceNorm + blend)
     if (msmp_tune_get("split") && msmp_tune_get("tail") && max_graph_nodes > 0 && max_graph_nodes <= 128) {
-        if (gated && (rc = aggregate(packed_gate, pre_gate))) return rc;       // pre_gate doubles as the gate head's aggregate
-        if ((rc = aggregate(packed_main, agg))) return rc;
+        rc = MSMP_ERR_UNSUPPORTED;
+        if (gated && fused && !dense)       // small batches: both heads per launch (projection, then message + mean)
+            rc = msmp_pair_project_aggregate(h, u, pos, vars, rowptr, col, tgt, n_nodes, n_edges, max_in_degree, tw, nv, packed_gate,
+                                             packed_main, pbuf, qbuf, pre_main, (float*)(ws + 5 * nod), pre_gate, agg, stream);
+        if (rc == MSMP_ERR_UNSUPPORTED) {
+            if (gated && (rc = aggregate(packed_gate, pre_gate))) return rc;       // pre_gate doubles as the gate head's aggregate
+            if ((rc = aggregate(packed_main, agg))) return rc;
+        } else if (rc) return rc;
         return msmp_node_tail_f32(h, agg, gated ? pre_gate : nullptr, vars, graph_ptr, n_nodes, n_graphs, max_graph_nodes, nv,
                                   packed_main, packed_gate, mode, eps, h_out, stream);
     }

@@ -385,6 +385,15 @@ __global__ __launch_bounds__(256, 2) void edge_mlp_kernel_occ2(EdgeArgs a) {
     edge_mlp_body<NB, FUSE, FACT, SPLIT>(a, lds);
 }
 
+struct EdgeArgs2 {
+    EdgeArgs head[2];
+};
+// both heads of a gated pair in one launch (blockIdx.y = head); see node_proj_split_pair_kernel
+__global__ __launch_bounds__(256, 2) void edge_mlp_pair_kernel_occ2(EdgeArgs2 a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
+    edge_mlp_body<1, true, true, true>(a.head[blockIdx.y], lds);
+}
+
 template <int NB, bool FUSE, bool FACT, bool SPLIT = false>
 __global__ __launch_bounds__(256, 3) void edge_mlp_kernel_occ3(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
@@ -688,8 +697,7 @@ __device__ __forceinline__ void mma_chunk_split_t(const float* wl, int lane, con
 // [32 nodes of the wave][channel 4 c + T], so a lane stores 16 consecutive bytes of whole 512-byte rows (16 stores per
 // matrix instead of 32 quarter-line pieces).  The tail chunk ([u, pos, vars] columns) is read with unconditional, clamped
 // loads and selected afterwards: predicated per-element loads compiled into serially waited-for blocks (27 % of the kernel).
-__global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs sa) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS + 2 * BTILE_FLOATS];
+__device__ __forceinline__ void node_proj_split_body(const ProjSplitArgs& sa, float* lds) {
     float* wbuf = lds;
     _Float16* bbuf = reinterpret_cast<_Float16*>(lds + 2 * SPLIT_CHUNK_FLOATS);
     const ProjArgs& a = sa.b;
@@ -805,6 +813,21 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs s
     }
     PROF_PROJ(7);
     PROF_PROJ_FLUSH
+}
+
+__global__ __launch_bounds__(256, 2) void node_proj_split_kernel(ProjSplitArgs sa) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS + 2 * BTILE_FLOATS];
+    node_proj_split_body(sa, lds);
+}
+
+// Both heads of a gated pair in ONE launch (blockIdx.y = head): same body, so the results are bit-identical to two launches.
+// Used for small batches, where a rollout step is a chain of ~60 dependent launches and each one is ~10 us of latency.
+struct ProjSplitArgs2 {
+    ProjSplitArgs head[2];
+};
+__global__ __launch_bounds__(256, 2) void node_proj_split_pair_kernel(ProjSplitArgs2 a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS + 2 * BTILE_FLOATS];
+    node_proj_split_body(a.head[blockIdx.y], lds);
 }
 
 // node_update keeps the per-lane row gather: with 50 KB less LDS three workgroups share a CU, which measured
@@ -1273,15 +1296,19 @@ extern int g_edge_ws_waves;
 static int g_edge_xcd = 0;   // XCD-contiguous tile order in the fused message kernels (msmp_tune "edge_xcd")
 static int g_edge_ws = 0;    // 1: persistent weight-stationary message + mean kernel (max in-degree <= 32; msmp_tune "edge_ws");
                              // measured equal to the streamed-weight kernel (2.43 vs 2.41 ms per step), so the latter stays the default
+static int g_pair = 1;       // gated pair: both heads' projection / message kernels in one launch each: 0 never, 1 up to PAIR_MAX_NODES nodes, 2 always
+constexpr int64_t PAIR_MAX_NODES = 65536;     // measured (E2, ms per rollout step, per-head vs paired): 256 graphs 1.33 / 1.14, 512: 2.06 / 1.95, 1024: 3.63 / 3.65, 2048: 6.95 / 7.07
 static int g_tail = 1;       // fused node tail (msmp_node_tail_f32) inside msmp_mp_layer_f32; msmp_tune("tail", 0) chains the pieces
 int msmp_tune_get(const char* key) {
     if (!strcmp(key, "split")) return g_split;
     if (!strcmp(key, "tail")) return g_tail;
+    if (!strcmp(key, "pair")) return g_pair;
     return 0;
 }
 
 extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "tail")) { g_tail = value; return MSMP_OK; }
+    if (key && !strcmp(key, "pair")) { g_pair = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_ws")) { g_edge_ws = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_xcd")) { g_edge_xcd = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_ws_waves")) { g_edge_ws_waves = value; return MSMP_OK; }
@@ -1333,6 +1360,42 @@ static int edge_aggregate(const float* h, const float* u, const float* pos, cons
     else hipLaunchKernelGGL((edge_mlp_kernel<2, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     timing_end(MSMP_K_EDGE_MLP, (hipStream_t)stream);
     return check_launch("edge_mlp_kernel<fused mean>");
+}
+
+// Projection + message + mean of BOTH heads of a gated pair with one launch per stage (library-internal; msmp_mp_layer_f32).
+// Returns MSMP_ERR_UNSUPPORTED (without setting an error text) when the configuration is not the default kernel path or the
+// batch is large: the caller then issues the per-head launches.  Same kernels bodies, bit-identical results.
+int msmp_pair_project_aggregate(const float* h, const float* u, const float* pos, const float* vars, const int32_t* rowptr,
+                                const int32_t* col, const int32_t* tgt, int64_t n_nodes, int64_t n_edges, int max_in_degree, int tw,
+                                int nv, const float* packed_a, const float* packed_b, float* p_a, float* q_a, float* p_b, float* q_b,
+                                float* agg_a, float* agg_b, msmp_stream_t stream) {
+    if (!g_pair || (g_pair == 1 && n_nodes > PAIR_MAX_NODES)) return MSMP_ERR_UNSUPPORTED;
+    if (!g_split || g_edge_ws || g_edge_occ != 2 || g_edge_nb == 2 || g_edge_xcd) return MSMP_ERR_UNSUPPORTED;
+    if (n_edges <= 0 || max_in_degree <= 0 || max_in_degree > 128 || n_edges >= (1L << 31) || n_nodes >= (1L << 31)) return MSMP_ERR_UNSUPPORTED;
+    const PackedLayout L = packed_layout(tw, nv);
+    hipStream_t st = (hipStream_t)stream;
+    ProjSplitArgs2 pa;
+    const float* packed[2] = {packed_a, packed_b};
+    float* pp[2] = {p_a, p_b};
+    float* qq[2] = {q_a, q_b};
+    float* agg[2] = {agg_a, agg_b};
+    for (int i = 0; i < 2; ++i)
+        pa.head[i] = ProjSplitArgs{ProjArgs{h, u, pos, vars, (long)n_nodes, tw, nv, L.nc1, packed[i] + L.w1, packed[i] + L.b1, pp[i], qq[i]},
+                                   packed[i] + L.w1t, packed[i] + L.scales};
+    timing_begin(MSMP_K_NODE_PROJ, st);
+    hipLaunchKernelGGL(node_proj_split_pair_kernel, dim3((unsigned)((n_nodes + 127) / 128), 2), dim3(256), 0, st, pa);
+    timing_end(MSMP_K_NODE_PROJ, st);
+    int tile_nodes = 128 / max_in_degree;
+    if (tile_nodes > 256) tile_nodes = 256;
+    EdgeArgs2 ea;
+    for (int i = 0; i < 2; ++i)
+        ea.head[i] = EdgeArgs{nullptr, nullptr, nullptr, nullptr, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, 0, tw, nv, L.nc1,
+                              packed[i] + L.w1, packed[i] + L.w2, packed[i] + L.w2s, packed[i] + L.scales, packed[i] + L.b1,
+                              packed[i] + L.b2, pp[i], qq[i], nullptr, agg[i]};
+    timing_begin(MSMP_K_EDGE_MLP, st);
+    hipLaunchKernelGGL(edge_mlp_pair_kernel_occ2, dim3((unsigned)((n_nodes + tile_nodes - 1) / tile_nodes), 2), dim3(256), 0, st, ea);
+    timing_end(MSMP_K_EDGE_MLP, st);
+    return check_launch("edge_mlp_pair_kernel_occ2");
 }
 
 extern "C" int msmp_edge_aggregate_f32(const float* h, const float* u, const float* pos, const float* vars,

@@ -5,7 +5,12 @@
 #include <stdio.h>
 #include "msmp_pde.h"
 
-int msmp_tune_get(const char* key);    // current value of a msmp_tune switch ("split", "tail"); library-internal
+int msmp_tune_get(const char* key);
+int msmp_pair_project_aggregate(const float* h, const float* u, const float* pos, const float* vars, const int32_t* rowptr,
+                                const int32_t* col, const int32_t* tgt, int64_t n_nodes, int64_t n_edges, int max_in_degree, int tw,
+                                int nv, const float* packed_a, const float* packed_b, float* p_a, float* q_a, float* p_b, float* q_b,
+                                float* agg_a, float* agg_b, msmp_stream_t stream);   // mlp_kernels.hip, library-internal
+    // current value of a msmp_tune switch ("split", "tail"); library-internal
 
 namespace msmp {
 

@@ -185,3 +185,24 @@ def test_fails_loudly_without_gpu_tensors(mp):
     with pytest.raises(Exception):
         with torch.no_grad():
             model(case.graph)
+
+
+def test_paired_head_launches_are_bit_identical(mp):
+    """msmp_tune("pair"): projecting / aggregating both heads of a gated pair in one launch each (the small-batch path) gives
+    the same bits as the per-head launches, on ragged-size batches either side of the automatic threshold."""
+    L = mp.lib()
+    try:
+        for exp, kind, bsz in (('E2', 'MP_PDE_SolverLEMLinGated', 3), ('WE3', 'MP_PDE_SolverGated', 37),
+                               ('RPU', 'MP_PDE_Solver2DLEMLinGated', 5)):
+            torch.manual_seed(2)
+            case = synthetic_case(mp, exp, bsz=bsz, seed=5)
+            model = getattr(mp, kind)(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=3).cuda().eval()
+            data = case.graph.to('cuda')
+            outs = []
+            for pair in (0, 2, 1):
+                L.msmp_tune(b'pair', pair)
+                with torch.no_grad():
+                    outs.append(model(data))
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    finally:
+        L.msmp_tune(b'pair', 1)

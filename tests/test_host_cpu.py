@@ -54,7 +54,7 @@ def test_argument_errors_are_reported_not_thrown(mp):
     assert L.msmp_packed_mlp2_floats(28) == 32 + 256 + (1 + 4) * 4096 and L.msmp_packed_mlp2_floats(129) == -1
     assert L.msmp_mlp2_input_stride(28) == 32 and L.msmp_mlp2_input_stride(59) == 64
     # knobs: known keys are accepted, unknown ones rejected with a message
-    for key in (b'split', b'edge_nb', b'edge_occ', b'edge_ws', b'edge_xcd', b'tail', b'lem', b'lem_nodes'):
+    for key in (b'split', b'edge_nb', b'edge_occ', b'edge_ws', b'edge_xcd', b'tail', b'pair', b'lem', b'lem_nodes'):
         assert L.msmp_tune(key, {b'split': 1, b'edge_occ': 2, b'tail': 1, b'lem': 3, b'lem_nodes': 1}.get(key, 0)) == 0, key
     assert L.msmp_tune(b'no_such_knob', 1) != 0 and b'unknown key' in L.msmp_last_error()
 
