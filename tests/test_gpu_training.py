@@ -26,7 +26,8 @@ def mp():
 @pytest.mark.parametrize('kind,exp', [('MP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'E2'), ('MP_PDE_Solver2DGated', 'RPU'),
                                       ('MP_PDE_SolverLEMLinGated', 'E2'), ('MP_PDE_Solver2DLEMLinGated', 'RPU'),
                                       ('MP_PDE_SolverLEMLin', 'E2'), ('MP_PDE_Solver2DLEMLinG2', 'RPU'),
-                                      ('MSSMP_PDE_Solver', 'E2')])
+                                      ('MSSMP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'WE3'),
+                                      ('MP_PDE_Solver2DLEMLinGated', 'MSWG3'), ('MP_PDE_Solver2D', 'RPU')])
 def test_gradients_match_float64_oracle(mp, kind, exp):
     """d loss / d parameters of the product (HIP forward, recompute backward, fp32) against torch autograd through
     the float64 oracle, for the reference's training loss sqrt(sum (pred - y)^2) (train_helper.py:126,138)."""
@@ -48,8 +49,14 @@ def test_gradients_match_float64_oracle(mp, kind, exp):
     # (GNN_LayerLin.update_net_2.bias) has an exactly-zero gradient, so per-tensor relative error is meaningless there
     scale = max(sd64[name].grad.abs().max().item() for name, _ in model.named_parameters())
     worst = 0.0
+    lin_layers = 'Gated' in kind or kind.endswith('G2') or kind.startswith('MSSMP')
     for name, p in model.named_parameters():
         g, r = p.grad.double().cpu(), sd64[name].grad
+        if lin_layers and name.endswith('update_net_2.0.bias'):
+            # GNN_LayerLin feeds its InstanceNorm directly: this gradient is analytically zero (both sides are rounding
+            # residue of sums of terms of size `scale`), so it gets an absolute bound instead of a relative one
+            assert (g - r).abs().max().item() < 1e-4 * scale, (name, (g - r).abs().max().item(), scale)
+            continue
         rel = (g - r).abs().max().item() / max(r.abs().max().item(), 1e-3 * scale)
         worst = max(worst, rel)
         assert rel < 2e-3, (name, rel)
