@@ -216,3 +216,33 @@ def test_paired_head_launches_are_bit_identical(mp):
             assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     finally:
         L.msmp_tune(b'pair', 1)
+
+
+@pytest.mark.parametrize('neighbors', [8, 16, 20])
+def test_large_neighbourhood_stress_vs_oracle(mp, neighbors):
+    """SURVEY 8(d) edge-count stress: MSWG3 (2-D classes, radius graph on linspace(0, 2 pi, 100)) with n = 8 / 16 neighbours per
+    side (in-degree up to 32 = torch_cluster's max_num_neighbors cap, 2 928 edges per graph at n = 16) and n = 20, where the cap
+    cuts every interior node's 40 candidates down to the 32 of lowest index.  edge_index bit-exact against the oracle's builder,
+    the solver output within the 1e-5 bar (fp32-oracle floor as in test_full_depth_vs_oracle), sharded = unsharded."""
+    from msmp_pde_amd.synthetic import make_case
+    torch.manual_seed(5)
+    c = make_case('MSWG3', 6, seed=3, device='cuda', neighbors=neighbors, dtype=torch.float64)
+    steps = [50] * 6
+    data, labels = c.creator.create_data(c.u_super, steps)
+    graph = c.creator.create_graph(data, labels, c.x, c.variables, steps)
+    x0 = c.x[0].numpy()
+    ei_ref = O.radius_graph(np.tile(x0, 6), neighbors * (x0[1] - x0[0]) + 0.0001, np.repeat(np.arange(6), 100))
+    assert np.array_equal(graph.edge_index.cpu().numpy(), ei_ref)
+    deg = np.bincount(ei_ref[1], minlength=600)
+    assert deg.max() == min(2 * neighbors, 32)
+    model = mp.MP_PDE_Solver2DLEMLinGated(c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=2).cuda().eval()
+    with torch.no_grad():
+        out = model(graph)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    from types import SimpleNamespace
+    g = SimpleNamespace(**{k: v.detach().cpu().numpy() for k, v in graph.__dict__.items() if torch.is_tensor(v)})
+    ref = O.solver_forward('MP_PDE_Solver2DLEMLinGated', sd, g, c.pde, TW, c.eqv, 2)
+    floor = np.abs(O.solver_forward('MP_PDE_Solver2DLEMLinGated', sd, g, c.pde, TW, c.eqv, 2, dtype=np.float32).astype(np.float64) - ref).max()
+    err = np.abs(out.double().cpu().numpy() - ref).max()
+    print(f'n={neighbors}: E/graph {ei_ref.shape[1] // 6}, max in-degree {deg.max()}, max|hip - oracle| = {err:.3e}, fp32 floor {floor:.3e}')
+    assert err < max(TOL, 8 * floor), (err, floor)
