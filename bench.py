@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--graphs', type=int, default=2048, help='graphs per GPU')
     ap.add_argument('--model', default='MSMP-PDE', help='MSMP-PDE | Gated | MP-PDE')
     ap.add_argument('--experiment', default='E2')
+    ap.add_argument('--neighbors', type=int, default=3, help='n of the graph builder (radius n*dx / knn k); 8, 16 = the MSWG3 edge-count stress of SURVEY 8(d)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-graphs', type=int, default=128)
     ap.add_argument('--cpu-sample-steps', type=int, default=3)
@@ -65,7 +66,7 @@ def cpu_baseline(args, kind, eqv):
     cores = min(avail, 16)          # the GPU box's CPU share for one GPU; BLAS threads actually used
     b = args.cpu_sample_graphs
     torch.manual_seed(0)
-    case = make_case(args.experiment, b, seed=0, device='cuda', dtype=torch.float64)
+    case = make_case(args.experiment, b, seed=0, device='cuda', dtype=torch.float64, neighbors=args.neighbors)
     model = mp.MODEL_NAMES[args.model](case.pde, time_window=25, eq_variables=eqv, hidden_layer=6)
     sd = {k: v.detach().numpy().astype(np.float64) for k, v in model.state_dict().items()}
     steps = [50] * b
@@ -118,7 +119,7 @@ def main():
     cls = mp.MODEL_NAMES[args.model]
     kind = cls.__name__
     torch.manual_seed(0)                       # same weights on every rank
-    case = make_case(exp, args.graphs, seed=1000 + rank, device=dev, dtype=torch.float32)
+    case = make_case(exp, args.graphs, seed=1000 + rank, device=dev, dtype=torch.float32, neighbors=args.neighbors)
     model = cls(case.pde, time_window=25, eq_variables=eqv, hidden_layer=6).to(dev).eval()
     bsz = args.graphs
     steps0 = [50] * bsz
@@ -187,7 +188,7 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{exp} {args.model} ({kind}), {bsz} graphs/GPU x nx=100, time_window=25, '
                                f'{"6 gated layer pairs" if model.GATED else "6 layers"}, '
-                               f'{"radius graph n=3" if exp in ("E2", "MSWG3") else "knn graph k=3"}', 'graphs_per_gpu': bsz, 'nodes': n_nodes,
+                               f'{"radius graph n=" if exp in ("E2", "MSWG3") else "knn graph k="}{args.neighbors}', 'graphs_per_gpu': bsz, 'nodes': n_nodes,
                    'edges': n_edges, 'parallelism': f'dp{world} (graph-sharded, no collective in the rollout)',
                    'graph_steps_per_s': total_steps * bsz / elapsed, 'output_finite': finite},
         # `achieved` counts the fp32 GEMM FLOPs the dominant kernel computes (conservative: the factorised form
