@@ -280,6 +280,22 @@ int msmp_lem_train_bwd_f32(const float* grad_y, const float* saved, int64_t n_no
  * re-evaluates the layer in materialised form with library GEMMs (the reference does the same through autograd over
  * experiments/models_gnn.py:61-149) and calls these between them.
  * ------------------------------------------------------------------------------------------- */
+/* The backward of msmp_mp_layer_f32 in one call: given grad_out = dL/d h_out it recomputes the layer (or the gated pair)
+ * from its inputs in materialised form and returns dh_out = dL/dh [N,128] and the gradients of the eight parameters of each
+ * layer (what torch.autograd produces over experiments/models_gnn.py:61-149 and the blend :1204-1207).  params_* / grads_*:
+ * arrays of 8 device pointers in the order message_net_1.0.weight, .bias, message_net_2.0.weight, .bias, update_net_1.0.weight,
+ * .bias, update_net_2.0.weight, .bias, in the reference's [out, in] layouts (NOT the packed blobs); gate arrays NULL for a
+ * single layer.  u, pos, vars carry no gradient.  GEMMs with edge- / node-sized outputs run on rocBLAS (looked up in the
+ * process at run time: MSMP_ERR_UNSUPPORTED if librocblas cannot be loaded); dh's source-side scatter uses atomics.
+ * Workspace: msmp_mp_layer_bwd_workspace_bytes (0 for invalid sizes). */
+size_t msmp_mp_layer_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int tw, int nv, int gated);
+int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, const float* u, const float* pos, const float* vars,
+                          const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const int32_t* graph_ptr,
+                          int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int tw, int nv,
+                          const float* const* params_main, const float* const* params_gate, int mode, float eps,
+                          float* dh_out, float* const* grads_main, float* const* grads_gate, void* workspace,
+                          size_t workspace_bytes, msmp_stream_t stream);
+
 /* The per-edge input of message_net_1 (models_gnn.py:69-75): out[e] = cat(h[i], h[j], u[i]-u[j], pos[i]-pos[j], vars[i]),
  * i = tgt[e], j = col[e]; out [E, ld] with ld >= 256 + tw + 1 + nv a multiple of 4 (columns past the concat are not written). */
 int msmp_edge_concat_f32(const float* h, const float* u, const float* pos, const float* vars, const int32_t* tgt,
@@ -298,12 +314,13 @@ int msmp_gate_blend_bwd_f32(const float* grad_out, const float* h, const float* 
                             float* dh_out, msmp_stream_t stream);
 
 /* Weight and bias gradients of up to 8 linear layers in one call (two launches):
- *   out[i] [128, k2+1] = ( a[i]^T b[i][:, :k2] | column sums of a[i] ),  a[i] [rows, 128] (row stride lda >= 128) =
- *   dL/d(pre-activation), b[i] [rows, k2] (row stride ldb >= k2, k2 <= 319) = that layer's input.  Exact-fp32 MFMA partial products over row
- *   splits, summed in a fixed order (deterministic).  workspace: msmp_grad_weights_workspace_floats floats. */
+ *   out_w[i] [128, k2] = a[i]^T b[i][:, :k2],  out_b[i] [128] = column sums of a[i];  a[i] [rows, 128] (row stride lda >= 128) =
+ *   dL/d(pre-activation), b[i] [rows, k2] (row stride ldb >= k2, k2 <= 319) = that layer's input.  Exact-fp32 MFMA partial
+ *   products over row splits, summed in a fixed order (deterministic).  workspace: msmp_grad_weights_workspace_floats floats. */
 int64_t msmp_grad_weights_workspace_floats(int n_jobs, const int64_t* rows, const int* k2);
 int msmp_grad_weights_f32(int n_jobs, const float* const* a, const float* const* b, const int64_t* rows, const int* lda,
-                          const int* ldb, const int* k2, float* const* out, float* workspace, int64_t workspace_floats, msmp_stream_t stream);
+                          const int* ldb, const int* k2, float* const* out_w, float* const* out_b, float* workspace,
+                          int64_t workspace_floats, msmp_stream_t stream);
 
 /* Two-layer node MLP  out = Swish(W2 Swish(W1 x + b1) + b2)  in one launch: the `embedding_mlp` encoder of the LEM-free
  * solver classes (experiments/models_gnn.py:196-201 called at :269-270; models_gnn2D.py:66-71 called at :119-120).

@@ -55,7 +55,10 @@ SIGNATURES = {
     'msmp_instance_norm_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     'msmp_gate_blend_bwd_f32': (c_int, [c_void_p] * 5 + [c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'msmp_grad_weights_workspace_floats': (c_int64, [c_int, c_void_p, c_void_p]),
-    'msmp_grad_weights_f32': (c_int, [c_int] + [c_void_p] * 8 + [c_int64, c_void_p]),
+    'msmp_grad_weights_f32': (c_int, [c_int] + [c_void_p] * 9 + [c_int64, c_void_p]),
+    'msmp_mp_layer_bwd_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
+    'msmp_mp_layer_bwd_f32': (c_int, [c_void_p] * 9 + [c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_float,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'msmp_packed_mlp2_floats': (c_int64, [c_int]),
     'msmp_mlp2_input_stride': (c_int, [c_int]),
     'msmp_pack_mlp2_f32': (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_void_p]),

@@ -1,11 +1,11 @@
 """Autograd support for the message-passing stack.
 
 Forward values always come from the HIP kernels (msmp_mp_layer_f32); only the layer's inputs are saved.  The backward
-pass RECOMPUTES the layer in materialised form and differentiates it with explicit formulas: every GEMM (data and weight
-gradients, K = E or N rows) is a library call (rocBLAS through torch.addmm / mm) and everything between the GEMMs is a HIP
-glue kernel of train_kernels.hip (edge concat, mean-backward + Swish', InstanceNorm backward, gated-blend backward) or one
-elementwise library op (silu / silu_backward).  ~65 launches per gated layer pair instead of the ~190 of differentiating a
-PyTorch restatement with torch.autograd (`EXPLICIT_BACKWARD = False` keeps that path for cross-checks).  Nothing runs on
+pass RECOMPUTES the layer in materialised form and differentiates it with explicit formulas, all of it behind ONE C-ABI call
+per layer / gated pair (msmp_mp_layer_bwd_f32, train_kernels.hip): GEMMs with edge- / node-sized outputs on rocBLAS, everything
+else HIP kernels (edge concat, bias + Swish, mean-backward + Swish', InstanceNorm backward, gated-blend backward, scatters,
+the batched weight-gradient kernel).  `EXPLICIT_BACKWARD = 1` runs the same algorithm orchestrated from Python (library GEMMs
+through torch, ~65 ops per pair), `0` differentiates a PyTorch restatement with torch.autograd (~190 ops): kept for cross-checks.  Nothing runs on
 the CPU and nothing here is used by the inference / rollout path.  The math is that of experiments/models_gnn.py:61-149
 and :1204-1207."""
 import torch
@@ -13,7 +13,33 @@ import torch.nn.functional as F
 
 from ._lib import lib, check, ptr, current_stream
 
-EXPLICIT_BACKWARD = True
+# 2: the whole layer backward behind the C-ABI (msmp_mp_layer_bwd_f32, launches issued from native code);
+# 1: the same algorithm orchestrated from Python (library GEMMs through torch); 0: torch.autograd over a restatement.
+EXPLICIT_BACKWARD = 2
+
+_bwd_ws = {}
+
+
+def layer_backward_native(gout, h, u, pos, variables, gs, params, mode_lin, gated, eps):
+    """dL/dh and the parameter gradients of one layer / gated pair through msmp_mp_layer_bwd_f32."""
+    import ctypes
+    L = lib()
+    dev = h.device
+    n, e, tw, nv = h.shape[0], gs.n_edges, u.shape[1], variables.shape[1]
+    ps = [q.detach() if (q.dtype == torch.float32 and q.is_contiguous()) else q.detach().to(torch.float32).contiguous() for q in params]
+    grads = [torch.empty(q.shape, dtype=torch.float32, device=dev) for q in ps]
+    dh = torch.empty(n, h.shape[1], dtype=torch.float32, device=dev)
+    g = gout if (gout.dtype == torch.float32 and gout.is_contiguous()) else gout.to(torch.float32).contiguous()
+    need = L.msmp_mp_layer_bwd_workspace_bytes(n, e, tw, nv, int(gated))
+    ws = _bwd_ws.get(dev)                       # grow-only scratch per device, like the forward's
+    if ws is None or ws.numel() < need:
+        ws = _bwd_ws[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+    arr = lambda ts: (ctypes.c_void_p * 8)(*[t.data_ptr() for t in ts])
+    check(L.msmp_mp_layer_bwd_f32(ptr(g), ptr(h), ptr(u), ptr(pos), ptr(variables), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt),
+                                  ptr(gs.graph_ptr), n, e, gs.n_graphs, tw, nv, arr(ps[:8]), arr(ps[8:]) if gated else None,
+                                  1 if (mode_lin or gated) else 0, eps, ptr(dh), arr(grads[:8]), arr(grads[8:]) if gated else None,
+                                  ptr(ws), ws.numel(), current_stream()), 'msmp_mp_layer_bwd_f32')
+    return dh, grads
 
 
 def _swish(x):
@@ -84,17 +110,18 @@ def grad_weights(pairs):
     k2 = (ctypes.c_int * n)(*[y.shape[1] for y in b])
     lda = (ctypes.c_int * n)(*[x.stride(0) for x in a])
     ldb = (ctypes.c_int * n)(*[y.stride(0) for y in b])
-    outs = [torch.empty(a[i].shape[1], b[i].shape[1] + 1, dtype=torch.float32, device=a[i].device) for i in range(n)]
+    out_w = [torch.empty(a[i].shape[1], b[i].shape[1], dtype=torch.float32, device=a[i].device) for i in range(n)]
+    out_b = [torch.empty(a[i].shape[1], dtype=torch.float32, device=a[i].device) for i in range(n)]
     ws_floats = L.msmp_grad_weights_workspace_floats(n, rows, k2)
     if ws_floats < 0:
         raise ValueError('grad_weights: unsupported shapes')
     ws = torch.empty(ws_floats, dtype=torch.float32, device=a[0].device)
     vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
-    check(L.msmp_grad_weights_f32(n, vp(a), vp(b), rows, lda, ldb, k2, vp(outs), ptr(ws), ws_floats, current_stream()),
+    check(L.msmp_grad_weights_f32(n, vp(a), vp(b), rows, lda, ldb, k2, vp(out_w), vp(out_b), ptr(ws), ws_floats, current_stream()),
           'msmp_grad_weights_f32')
     res = []
-    for o in outs:
-        res += [o[:, :-1], o[:, -1]]
+    for w, bias in zip(out_w, out_b):
+        res += [w, bias]
     return res
 
 
@@ -177,7 +204,8 @@ class MPLayerFunction(torch.autograd.Function):
         gs, mode, gated, eps = ctx.meta
         if EXPLICIT_BACKWARD:
             with torch.no_grad():
-                dh, grads = layer_backward_explicit(gout, h, u, pos, variables, gs, params, mode == 1, gated, eps)
+                fn = layer_backward_native if EXPLICIT_BACKWARD == 2 else layer_backward_explicit
+                dh, grads = fn(gout, h, u, pos.reshape(-1), variables, gs, params, mode == 1, gated, eps)
             return (dh, None, None, None, None, None, None, None, None) + tuple(grads)
         src, dst = gs.col[:gs.n_edges].long(), gs.tgt[:gs.n_edges].long()
         sizes = (gs.graph_ptr[1:] - gs.graph_ptr[:-1]).long()

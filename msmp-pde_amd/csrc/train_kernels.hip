@@ -35,7 +35,7 @@ __device__ __forceinline__ float dswish(float x) {        // d/dx x sigmoid(x)
 }
 
 // da2[e] = dagg[tgt[e]] / max(deg, 1) * Swish'(a2[e]);  thread = (edge, 16-B channel group)
-__global__ __launch_bounds__(256) void mean_bwd_dswish_kernel(const float* __restrict__ dagg, const int* __restrict__ rowptr,
+__global__ __launch_bounds__(256) void mean_bwd_dswish_kernel(const float* __restrict__ dagg, int ld, const int* __restrict__ rowptr,
                                                               const int* __restrict__ tgt, const float* __restrict__ a2,
                                                               long n_edges, float* __restrict__ out) {
     const long total = n_edges * (H / 4);
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void mean_bwd_dswish_kernel(const float* __res
         const long e = p >> 5;
         const int cg = (int)(p & 31), i = tgt[e];
         const float inv = 1.0f / (float)max(rowptr[i + 1] - rowptr[i], 1);
-        const f32x4 g = reinterpret_cast<const f32x4*>(dagg)[(size_t)i * (H / 4) + cg];
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dagg + (size_t)i * ld + 4 * cg);
         const f32x4 a = reinterpret_cast<const f32x4*>(a2)[p];
         f32x4 r;
 #pragma unroll
@@ -158,7 +158,7 @@ extern "C" int msmp_mean_bwd_dswish_f32(const float* dagg, const int32_t* rowptr
     if (n_edges == 0) return MSMP_OK;
     const long blocks = (n_edges * (H / 4) + 255) / 256;
     hipLaunchKernelGGL(mean_bwd_dswish_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, dagg,
-                       rowptr, tgt, a2, (long)n_edges, out);
+                       H, rowptr, tgt, a2, (long)n_edges, out);
     return check_launch("mean_bwd_dswish_kernel");
 }
 
@@ -195,7 +195,8 @@ constexpr int GW_MAX_JOBS = 8;
 struct GradWeightJob {
     const float* a;      // [rows, lda], columns 0..127 used
     const float* b;      // [rows, ldb], columns 0..k2-1 used
-    float* out;          // [128, k2 + 1]: dW | db
+    float* out_w;        // [128, k2]
+    float* out_b;        // [128]
     float* partial;      // [splits][128][32 * nt]
     int rows, lda, ldb, k2, nt, rows_per_split, splits, first_block;
 };
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(256) void grad_weight_reduce_kernel(GradWeightArgs 
         const float* src = j.partial + (size_t)row * ldp + c;
         float s = 0.f;
         for (int k = 0; k < j.splits; ++k) s += src[(size_t)k * H * ldp];
-        j.out[p] = s;
+        if (c < j.k2) j.out_w[(size_t)row * j.k2 + c] = s;
+        else j.out_b[row] = s;
     }
 }
 
@@ -296,22 +298,22 @@ extern "C" int64_t msmp_grad_weights_workspace_floats(int n_jobs, const int64_t*
     return total;
 }
 
-extern "C" int msmp_grad_weights_f32(int n_jobs, const float* const* a, const float* const* b, const int64_t* rows, const int* lda,
-                                     const int* ldb, const int* k2, float* const* out, float* workspace, int64_t workspace_floats,
-                                     msmp_stream_t stream) {
-    MSMP_REQUIRE(n_jobs >= 1 && n_jobs <= GW_MAX_JOBS, MSMP_ERR_ARG, "msmp_grad_weights_f32: n_jobs=%d not in 1..%d", n_jobs, GW_MAX_JOBS);
-    MSMP_REQUIRE(a && b && rows && lda && ldb && k2 && out && workspace, MSMP_ERR_ARG, "msmp_grad_weights_f32: null pointer");
+namespace msmp {
+// launches of msmp_grad_weights_f32 on validated arguments (also used by the layer backward below)
+static int launch_grad_weights(int n_jobs, const float* const* a, const float* const* b, const int64_t* rows, const int* lda,
+                               const int* ldb, const int* k2, float* const* out_w, float* const* out_b, float* workspace,
+                               int64_t workspace_floats, hipStream_t stream) {
     GradWeightArgs args;
     args.n_jobs = n_jobs;
     int64_t used = 0;
     int blocks = 0, max_w = 0;
     for (int i = 0; i < n_jobs; ++i) {
-        MSMP_REQUIRE(a[i] && b[i] && out[i], MSMP_ERR_ARG, "msmp_grad_weights_f32: null pointer in job %d", i);
+        MSMP_REQUIRE(a[i] && b[i] && out_w[i] && out_b[i], MSMP_ERR_ARG, "msmp_grad_weights_f32: null pointer in job %d", i);
         MSMP_REQUIRE(rows[i] >= 1 && rows[i] < (1L << 31) && k2[i] >= 1 && ldb[i] >= k2[i] && lda[i] >= H, MSMP_ERR_ARG, "msmp_grad_weights_f32: bad sizes in job %d", i);
         const int nt = gw_tiles(k2[i]);
         MSMP_REQUIRE(nt > 0, MSMP_ERR_UNSUPPORTED, "msmp_grad_weights_f32: k2=%d > 319", k2[i]);
         GradWeightJob& j = args.job[i];
-        j.a = a[i]; j.b = b[i]; j.out = out[i]; j.partial = workspace + used;
+        j.a = a[i]; j.b = b[i]; j.out_w = out_w[i]; j.out_b = out_b[i]; j.partial = workspace + used;
         j.rows = (int)rows[i]; j.lda = lda[i]; j.ldb = ldb[i]; j.k2 = k2[i]; j.nt = nt;
         j.rows_per_split = gw_rows_per_split(rows[i]);
         j.splits = (j.rows + j.rows_per_split - 1) / j.rows_per_split;
@@ -321,9 +323,322 @@ extern "C" int msmp_grad_weights_f32(int n_jobs, const float* const* a, const fl
         max_w = k2[i] + 1 > max_w ? k2[i] + 1 : max_w;
     }
     for (int i = n_jobs; i < GW_MAX_JOBS; ++i) args.job[i] = args.job[0];
-    MSMP_REQUIRE(used <= workspace_floats, MSMP_ERR_ARG, "msmp_grad_weights_f32: workspace of %ld floats, need %ld", (long)workspace_floats, (long)used);
-    hipLaunchKernelGGL(grad_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, args);
-    hipLaunchKernelGGL(grad_weight_reduce_kernel, dim3((unsigned)((H * max_w + 255) / 256), (unsigned)n_jobs), dim3(256), 0,
-                       (hipStream_t)stream, args);
+    MSMP_REQUIRE(used <= workspace_floats, MSMP_ERR_WORKSPACE, "msmp_grad_weights_f32: workspace of %ld floats, need %ld", (long)workspace_floats, (long)used);
+    hipLaunchKernelGGL(grad_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(grad_weight_reduce_kernel, dim3((unsigned)((H * max_w + 255) / 256), (unsigned)n_jobs), dim3(256), 0, stream, args);
     return check_launch("grad_weight_kernel");
+}
+}  // namespace msmp
+
+extern "C" int msmp_grad_weights_f32(int n_jobs, const float* const* a, const float* const* b, const int64_t* rows, const int* lda,
+                                     const int* ldb, const int* k2, float* const* out_w, float* const* out_b, float* workspace,
+                                     int64_t workspace_floats, msmp_stream_t stream) {
+    MSMP_REQUIRE(n_jobs >= 1 && n_jobs <= GW_MAX_JOBS, MSMP_ERR_ARG, "msmp_grad_weights_f32: n_jobs=%d not in 1..%d", n_jobs, GW_MAX_JOBS);
+    MSMP_REQUIRE(a && b && rows && lda && ldb && k2 && out_w && out_b && workspace, MSMP_ERR_ARG, "msmp_grad_weights_f32: null pointer");
+    return launch_grad_weights(n_jobs, a, b, rows, lda, ldb, k2, out_w, out_b, workspace, workspace_floats, (hipStream_t)stream);
+}
+
+// ==============================================================================================
+// msmp_mp_layer_bwd_f32: the whole backward of one layer / one gated pair behind the C-ABI (the `_bwd` variant of
+// msmp_mp_layer_f32): recompute in materialised form, the gated-blend / InstanceNorm backward, the
+// data-gradient chain and the eight (sixteen) parameter gradients -- ~60 launches issued from native code instead of ~65
+// library ops issued from Python (at the reference's batch of 16 graphs the host was the bound).  GEMMs with edge- or
+// node-sized outputs go to rocBLAS (`rocblas_sgemm`, looked up at run time in the librocblas the process already has:
+// inference never needs it); everything else is the kernels of this file.
+// ==============================================================================================
+#include <dlfcn.h>
+#include <rocblas/rocblas.h>
+
+namespace msmp {
+
+struct Blas {
+    rocblas_handle handle = nullptr;
+    rocblas_status (*sgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const float*,
+                            const float*, rocblas_int, const float*, rocblas_int, const float*, float*, rocblas_int) = nullptr;
+    rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
+    bool tried = false;
+};
+
+static Blas& blas() {
+    static thread_local Blas b;          // one handle per calling thread (the autograd engine calls from its own)
+    if (!b.tried) {
+        b.tried = true;
+        void* lib = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) {
+            auto create = reinterpret_cast<rocblas_status (*)(rocblas_handle*)>(dlsym(lib, "rocblas_create_handle"));
+            b.sgemm = reinterpret_cast<decltype(b.sgemm)>(dlsym(lib, "rocblas_sgemm"));
+            b.set_stream = reinterpret_cast<decltype(b.set_stream)>(dlsym(lib, "rocblas_set_stream"));
+            if (!create || !b.sgemm || !b.set_stream || create(&b.handle) != rocblas_status_success) b.handle = nullptr;
+        }
+    }
+    return b;
+}
+
+// row-major helpers on the column-major library (a row-major [R,C] matrix with stride ld is the column-major [C,R] one)
+//   C[M,N] = A[M,K] W[N,K]^T      (a linear layer's forward)
+static rocblas_status gemm_nt(Blas& b, int M, int N, int K, const float* A, int lda, const float* W, int ldw, float* C, int ldc) {
+    const float one = 1.f, zero = 0.f;
+    return b.sgemm(b.handle, rocblas_operation_transpose, rocblas_operation_none, N, M, K, &one, W, ldw, A, lda, &zero, C, ldc);
+}
+//   C[M,K2] = G[M,N] W[N, :K2]    (its data gradient; W's row stride ldw >= K2)
+static rocblas_status gemm_nn(Blas& b, int M, int K2, int N, const float* G, int ldg, const float* W, int ldw, float* C, int ldc) {
+    const float one = 1.f, zero = 0.f;
+    return b.sgemm(b.handle, rocblas_operation_none, rocblas_operation_none, K2, M, N, &one, W, ldw, G, ldg, &zero, C, ldc);
+}
+
+// ---- elementwise glue on [rows, 128] tensors (thread = 16-byte channel group) ----------------------------------------
+__global__ __launch_bounds__(256) void bias_silu_kernel(float* __restrict__ a, const float* __restrict__ bias, float* __restrict__ m, long n4) {
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n4; p += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<f32x4*>(a)[p] + reinterpret_cast<const f32x4*>(bias)[p & 31];
+        reinterpret_cast<f32x4*>(a)[p] = v;
+        if (m) {
+            f32x4 r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = swishf(v[i]);
+            reinterpret_cast<f32x4*>(m)[p] = r;
+        }
+    }
+}
+
+// out = g * Swish'(a)   (out may alias g)
+__global__ __launch_bounds__(256) void dsilu_mul_kernel(const float* g, const float* __restrict__ a, float* out, long n4) {
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n4; p += (long)gridDim.x * blockDim.x) {
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[p], av = reinterpret_cast<const f32x4*>(a)[p];
+        f32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = gv[i] * dswish(av[i]);
+        reinterpret_cast<f32x4*>(out)[p] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, float v, long n) {
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) x[p] = v;
+}
+
+// out = h + Swish(upd)   (GNN_Layer's pre-norm tensor)
+__global__ __launch_bounds__(256) void residual_silu_kernel(const float* __restrict__ h, const float* __restrict__ upd, float* __restrict__ out, long n4) {
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n4; p += (long)gridDim.x * blockDim.x) {
+        const f32x4 hv = reinterpret_cast<const f32x4*>(h)[p], uv = reinterpret_cast<const f32x4*>(upd)[p];
+        f32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = hv[i] + swishf(uv[i]);
+        reinterpret_cast<f32x4*>(out)[p] = r;
+    }
+}
+
+// the input of update_net_1: out[n] = [h[n] | agg[n] | vars[n]]  (row stride ld, a multiple of 4)
+__global__ __launch_bounds__(256) void cat_node_kernel(const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ vars,
+                                                       long n_nodes, int nv, int ld, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long)gridDim.x * 4;
+    for (long n = wave; n < n_nodes; n += n_waves) {
+        float* row = out + (size_t)n * ld;
+        const float* src = lane < 32 ? h : agg;
+        *reinterpret_cast<f32x4*>(row + 4 * lane) = *reinterpret_cast<const f32x4*>(src + (size_t)n * H + 4 * (lane & 31));
+        if (lane < nv) row[2 * H + lane] = vars[(size_t)n * nv + lane];
+    }
+}
+
+// dh[n] += x[n][0..127]   (x row stride ld)
+__global__ __launch_bounds__(256) void add_cols_kernel(float* __restrict__ dh, const float* __restrict__ x, int ld, long n_nodes) {
+    const long total = n_nodes * (H / 4);
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const long n = p >> 5;
+        const int cg = (int)(p & 31);
+        reinterpret_cast<f32x4*>(dh)[p] += *reinterpret_cast<const f32x4*>(x + (size_t)n * ld + 4 * cg);
+    }
+}
+
+// dh[i] += sum over the in-edges e of i of d[e][0..127]   (CSR order: deterministic), thread = (node, channel group)
+__global__ __launch_bounds__(256) void scatter_target_kernel(float* __restrict__ dh, const float* __restrict__ d, int ld,
+                                                             const int* __restrict__ rowptr, long n_nodes) {
+    const long total = n_nodes * (H / 4);
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const long n = p >> 5;
+        const int cg = (int)(p & 31);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) s += *reinterpret_cast<const f32x4*>(d + (size_t)e * ld + 4 * cg);
+        reinterpret_cast<f32x4*>(dh)[p] += s;
+    }
+}
+
+// dh[col[e]] += d[e][128..255]   (the source side: atomics, order not fixed)
+__global__ __launch_bounds__(256) void scatter_source_kernel(float* __restrict__ dh, const float* __restrict__ d, int ld,
+                                                             const int* __restrict__ col, long n_edges) {
+    const long total = n_edges * H;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const long e = p >> 7;
+        const int c = (int)(p & 127);
+        atomicAdd(dh + (size_t)col[e] * H + c, d[(size_t)e * ld + H + c]);
+    }
+}
+
+static unsigned grid_for(long work_items) {
+    const long b = (work_items + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : b > 32768 ? 32768 : b);
+}
+
+struct BwdCtx {
+    const float *h, *u, *pos, *vars;
+    const int32_t *rowptr, *col, *tgt, *graph_ptr;
+    long n, e, g;
+    int tw, nv, kmsg, kupd, ld_e, ld_n;
+    hipStream_t st;
+};
+
+struct HeadBuf {      // per head: recompute intermediates and gradient scratch
+    float *cat_e, *a1, *m1, *a2, *x2, *x1, *dcat_e;             // edge-sized: [E, ld_e], 5 x [E,128], [E,256]
+    float *agg, *cat_n, *a3, *u1, *upd, *dupd, *x3, *dcat_n;    // node-sized: [N,128], [N, ld_n], 5 x [N,128], [N,256]
+};
+
+static size_t head_floats(long n, long e, int ld_e, int ld_n) {
+    return (size_t)e * (ld_e + 5 * H + 2 * H) + (size_t)n * (H + ld_n + 5 * H + 2 * H);
+}
+
+static void carve(float*& p, long n, long e, int ld_e, int ld_n, HeadBuf& b) {
+    auto take = [&](size_t k) { float* r = p; p += (k + 63) / 64 * 64; return r; };
+    b.cat_e = take((size_t)e * ld_e); b.a1 = take((size_t)e * H); b.m1 = take((size_t)e * H); b.a2 = take((size_t)e * H);
+    b.x2 = take((size_t)e * H); b.x1 = take((size_t)e * H); b.dcat_e = take((size_t)e * 2 * H);
+    b.agg = take((size_t)n * H); b.cat_n = take((size_t)n * ld_n); b.a3 = take((size_t)n * H); b.u1 = take((size_t)n * H);
+    b.upd = take((size_t)n * H); b.dupd = take((size_t)n * H); b.x3 = take((size_t)n * H); b.dcat_n = take((size_t)n * 2 * H);
+}
+
+#define BLAS_OK(call, what) do { if ((call) != rocblas_status_success) { set_error("msmp_mp_layer_bwd_f32: rocblas_sgemm failed (%s)", what); return MSMP_ERR_HIP; } } while (0)
+#define RC(call) do { const int rc_ = (call); if (rc_) return rc_; } while (0)
+
+// upd = W4 Swish(W3 [h, mean_j Swish(W2 Swish(W1 cat_e + b1) + b2), vars] + b3) + b4, keeping the pre-activations
+static int head_recompute(const BwdCtx& c, Blas& bl, const float* const* p, HeadBuf& b) {
+    const long n = c.n, e = c.e;
+    if (e) {
+        RC(msmp_edge_concat_f32(c.h, c.u, c.pos, c.vars, c.tgt, c.col, e, c.tw, c.nv, c.ld_e, b.cat_e, c.st));
+        BLAS_OK(gemm_nt(bl, (int)e, H, c.kmsg, b.cat_e, c.ld_e, p[0], c.kmsg, b.a1, H), "message_net_1");
+        hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.a1, p[1], b.m1, e * 32);
+        BLAS_OK(gemm_nt(bl, (int)e, H, H, b.m1, H, p[2], H, b.a2, H), "message_net_2");
+        hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.a2, p[3], b.x2, e * 32);
+        RC(msmp_scatter_mean_f32(b.x2, c.rowptr, n, b.agg, c.st));
+    } else
+        hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n * H)), dim3(256), 0, c.st, b.agg, 0.f, n * H);
+    hipLaunchKernelGGL(cat_node_kernel, dim3(grid_for(n * 64)), dim3(256), 0, c.st, c.h, b.agg, c.vars, n, c.nv, c.ld_n, b.cat_n);
+    BLAS_OK(gemm_nt(bl, (int)n, H, c.kupd, b.cat_n, c.ld_n, p[4], c.kupd, b.a3, H), "update_net_1");
+    hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, b.a3, p[5], b.u1, n * 32);
+    BLAS_OK(gemm_nt(bl, (int)n, H, H, b.u1, H, p[6], H, b.upd, H), "update_net_2");
+    hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, b.upd, p[7], (float*)nullptr, n * 32);
+    return check_launch("layer backward: recompute");
+}
+
+struct GwJobs {
+    const float *a[GW_MAX_JOBS], *b[GW_MAX_JOBS];
+    int64_t rows[GW_MAX_JOBS];
+    int lda[GW_MAX_JOBS], ldb[GW_MAX_JOBS], k2[GW_MAX_JOBS];
+    float *out_w[GW_MAX_JOBS], *out_b[GW_MAX_JOBS];
+    int n = 0;
+    void add(const float* a_, const float* b_, int64_t rows_, int ldb_, int k2_, float* w, float* bias) {
+        a[n] = a_; b[n] = b_; rows[n] = rows_; lda[n] = H; ldb[n] = ldb_; k2[n] = k2_; out_w[n] = w; out_b[n] = bias; ++n;
+    }
+};
+
+// b.dupd = dL/d upd  ->  dh += dL/dh through this head; the four (gradient, input) pairs are queued for the weight-gradient kernel
+static int head_backward(const BwdCtx& c, Blas& bl, const float* const* p, HeadBuf& b, float* dh, float* const* grads, GwJobs& jobs) {
+    const long n = c.n, e = c.e;
+    BLAS_OK(gemm_nn(bl, (int)n, H, H, b.dupd, H, p[6], H, b.x3, H), "d update_net_2");
+    hipLaunchKernelGGL(dsilu_mul_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, b.x3, b.a3, b.x3, n * 32);                 // d a3
+    BLAS_OK(gemm_nn(bl, (int)n, 2 * H, H, b.x3, H, p[4], c.kupd, b.dcat_n, 2 * H), "d update_net_1");                            // [dh | dagg]
+    hipLaunchKernelGGL(add_cols_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, dh, b.dcat_n, 2 * H, n);
+    if (e) {
+        hipLaunchKernelGGL(mean_bwd_dswish_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.dcat_n + H, 2 * H, c.rowptr, c.tgt, b.a2, e, b.x2);   // d a2
+        BLAS_OK(gemm_nn(bl, (int)e, H, H, b.x2, H, p[2], H, b.x1, H), "d message_net_2");
+        hipLaunchKernelGGL(dsilu_mul_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.x1, b.a1, b.x1, e * 32);             // d a1
+        BLAS_OK(gemm_nn(bl, (int)e, 2 * H, H, b.x1, H, p[0], c.kmsg, b.dcat_e, 2 * H), "d message_net_1");                      // [d x_i | d x_j]
+        hipLaunchKernelGGL(scatter_target_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.rowptr, n);
+        hipLaunchKernelGGL(scatter_source_kernel, dim3(grid_for(e * H)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.col, e);
+        jobs.add(b.x1, b.cat_e, e, c.ld_e, c.kmsg, grads[0], grads[1]);
+        jobs.add(b.x2, b.m1, e, H, H, grads[2], grads[3]);
+    } else {          // no edges: the message layers get zero gradients
+        hipLaunchKernelGGL(fill_kernel, dim3(grid_for((long)H * c.kmsg)), dim3(256), 0, c.st, grads[0], 0.f, (long)H * c.kmsg);
+        hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, c.st, grads[1], 0.f, (long)H);
+        hipLaunchKernelGGL(fill_kernel, dim3(grid_for((long)H * H)), dim3(256), 0, c.st, grads[2], 0.f, (long)H * H);
+        hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, c.st, grads[3], 0.f, (long)H);
+    }
+    jobs.add(b.x3, b.cat_n, n, c.ld_n, c.kupd, grads[4], grads[5]);
+    jobs.add(b.dupd, b.u1, n, H, H, grads[6], grads[7]);
+    return check_launch("layer backward: data gradients");
+}
+
+static int64_t bwd_gw_floats(long n, long e, int kmsg, int kupd, int heads) {
+    int64_t rows[GW_MAX_JOBS];
+    int k2[GW_MAX_JOBS], j = 0;
+    for (int hd = 0; hd < heads; ++hd) {
+        if (e) { rows[j] = e; k2[j++] = kmsg; rows[j] = e; k2[j++] = H; }
+        rows[j] = n; k2[j++] = kupd; rows[j] = n; k2[j++] = H;
+    }
+    return msmp_grad_weights_workspace_floats(j, rows, k2);
+}
+
+}  // namespace msmp
+
+extern "C" size_t msmp_mp_layer_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int tw, int nv, int gated) {
+    if (n_nodes <= 0 || n_edges < 0 || tw < 1 || nv < 1 || nv > MSMP_MAX_VARS) return 0;
+    const int kmsg = 2 * H + tw + 1 + nv, kupd = 2 * H + nv, ld_e = (kmsg + 3) / 4 * 4, ld_n = (kupd + 3) / 4 * 4;
+    const int heads = gated ? 2 : 1;
+    const int64_t gw = bwd_gw_floats(n_nodes, n_edges, kmsg, kupd, heads);
+    if (gw < 0) return 0;
+    return (heads * (head_floats(n_nodes, n_edges, ld_e, ld_n) + 15 * 64) + (size_t)gw + 64) * sizeof(float) + 256;
+}
+
+extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, const float* u, const float* pos, const float* vars,
+                                     const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const int32_t* graph_ptr,
+                                     int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int tw, int nv,
+                                     const float* const* params_main, const float* const* params_gate, int mode, float eps,
+                                     float* dh_out, float* const* grads_main, float* const* grads_gate, void* workspace,
+                                     size_t workspace_bytes, msmp_stream_t stream) {
+    MSMP_REQUIRE(grad_out && h && u && pos && vars && rowptr && col && tgt && graph_ptr && params_main && dh_out && grads_main && workspace,
+                 MSMP_ERR_ARG, "msmp_mp_layer_bwd_f32: null pointer");
+    MSMP_REQUIRE((params_gate != nullptr) == (grads_gate != nullptr), MSMP_ERR_ARG, "msmp_mp_layer_bwd_f32: give both gate arguments or none");
+    const bool gated = params_gate != nullptr;
+    MSMP_REQUIRE(mode == MSMP_LAYER_LIN || mode == MSMP_LAYER_RESIDUAL_SWISH, MSMP_ERR_ARG, "msmp_mp_layer_bwd_f32: bad mode %d", mode);
+    MSMP_REQUIRE(!gated || mode == MSMP_LAYER_LIN, MSMP_ERR_ARG, "msmp_mp_layer_bwd_f32: the gated pair uses GNN_LayerLin layers");
+    MSMP_REQUIRE(n_nodes > 0 && n_edges >= 0 && n_graphs > 0 && n_nodes < (1L << 31) && n_edges < (1L << 31) && tw >= 1 && nv >= 1 &&
+                     nv <= MSMP_MAX_VARS && tw + 1 + nv <= 64, MSMP_ERR_ARG, "msmp_mp_layer_bwd_f32: bad sizes");
+    for (int i = 0; i < 8; ++i) {
+        MSMP_REQUIRE(params_main[i] && grads_main[i], MSMP_ERR_ARG, "msmp_mp_layer_bwd_f32: null parameter / gradient pointer %d", i);
+        MSMP_REQUIRE(!gated || (params_gate[i] && grads_gate[i]), MSMP_ERR_ARG, "msmp_mp_layer_bwd_f32: null gate parameter / gradient pointer %d", i);
+    }
+    const size_t need = msmp_mp_layer_bwd_workspace_bytes(n_nodes, n_edges, tw, nv, gated);
+    MSMP_REQUIRE(need && workspace_bytes >= need, MSMP_ERR_WORKSPACE, "msmp_mp_layer_bwd_f32: workspace %zu < %zu", workspace_bytes, need);
+    Blas& bl = blas();
+    MSMP_REQUIRE(bl.handle, MSMP_ERR_UNSUPPORTED, "msmp_mp_layer_bwd_f32: librocblas (rocblas_sgemm) is not available in this process");
+    hipStream_t st = (hipStream_t)stream;
+    MSMP_REQUIRE(bl.set_stream(bl.handle, st) == rocblas_status_success, MSMP_ERR_HIP, "msmp_mp_layer_bwd_f32: rocblas_set_stream failed");
+
+    BwdCtx c{h, u, pos, vars, rowptr, col, tgt, graph_ptr, (long)n_nodes, (long)n_edges, (long)n_graphs, tw, nv,
+             2 * H + tw + 1 + nv, 2 * H + nv, 0, 0, st};
+    c.ld_e = (c.kmsg + 3) / 4 * 4;
+    c.ld_n = (c.kupd + 3) / 4 * 4;
+    float* p = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    HeadBuf bm, bg;
+    carve(p, c.n, c.e, c.ld_e, c.ld_n, bm);
+    if (gated) carve(p, c.n, c.e, c.ld_e, c.ld_n, bg);
+    float* gw_ws = p;
+    const int64_t gw_floats = bwd_gw_floats(c.n, c.e, c.kmsg, c.kupd, gated ? 2 : 1);
+    const long n4 = c.n * 32;
+    GwJobs jobs;
+
+    RC(head_recompute(c, bl, params_main, bm));
+    if (gated) {
+        RC(head_recompute(c, bl, params_gate, bg));
+        RC(msmp_gate_blend_bwd_f32(grad_out, h, bg.upd, bm.upd, graph_ptr, n_graphs, eps, bg.dupd, bm.dupd, dh_out, stream));
+        RC(head_backward(c, bl, params_main, bm, dh_out, grads_main, jobs));
+        RC(head_backward(c, bl, params_gate, bg, dh_out, grads_gate, jobs));
+    } else if (mode == MSMP_LAYER_LIN) {          // out = IN(upd): no direct path to h
+        RC(msmp_instance_norm_bwd_f32(bm.upd, grad_out, graph_ptr, n_graphs, eps, bm.dupd, stream));
+        hipLaunchKernelGGL(fill_kernel, dim3(grid_for(c.n * H)), dim3(256), 0, st, dh_out, 0.f, c.n * H);
+        RC(head_backward(c, bl, params_main, bm, dh_out, grads_main, jobs));
+    } else {                                      // out = IN(h + Swish(upd))
+        hipLaunchKernelGGL(residual_silu_kernel, dim3(grid_for(n4)), dim3(256), 0, st, h, bm.upd, bm.dcat_n, n4);
+        RC(msmp_instance_norm_bwd_f32(bm.dcat_n, grad_out, graph_ptr, n_graphs, eps, dh_out, stream));
+        hipLaunchKernelGGL(dsilu_mul_kernel, dim3(grid_for(n4)), dim3(256), 0, st, dh_out, bm.upd, bm.dupd, n4);
+        RC(head_backward(c, bl, params_main, bm, dh_out, grads_main, jobs));
+    }
+    return launch_grad_weights(jobs.n, jobs.a, jobs.b, jobs.rows, jobs.lda, jobs.ldb, jobs.k2, jobs.out_w, jobs.out_b, gw_ws, gw_floats, st);
 }
