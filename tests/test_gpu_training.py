@@ -269,3 +269,45 @@ def test_grad_weights_kernel_shapes_and_strides(mp):
     assert all(torch.equal(x, y) for x, y in zip(out, again))
     with pytest.raises(ValueError):
         grad_weights([(pairs[0][0], torch.randn(1, 320).cuda())])              # k2 > 319
+
+
+@pytest.mark.parametrize('form', ['residual', 'lin', 'gated'])
+@pytest.mark.parametrize('n_edges', [0, 900])
+def test_layer_backward_entry_vs_float64_autograd(mp, form, n_edges):
+    """msmp_mp_layer_bwd_f32 through the C-ABI on ragged graphs (1, 100, 3, 130, 2 nodes; nodes without in-edges; an edgeless
+    batch): dL/dh and all parameter gradients against float64 torch.autograd over the restatement of the layer."""
+    from msmp_pde_amd import autograd as A
+    from msmp_pde_amd.graph import GraphStructure
+    g = torch.Generator(device='cpu').manual_seed(21)
+    sizes = [1, 100, 3, 130, 2]
+    gp, batch = _ragged(sizes)
+    n, tw, nv, eps = sum(sizes), 25, 3, 1e-5
+    r = lambda *s: torch.randn(*s, generator=g).cuda()
+    # edges inside graph 1 and graph 3 only, no self-loops needed for the test; the last nodes of each stay without in-edges
+    src = torch.cat([torch.randint(1, 90, (n_edges // 2,), generator=g), torch.randint(104, 220, (n_edges - n_edges // 2,), generator=g)])
+    dst = torch.cat([torch.randint(1, 90, (n_edges // 2,), generator=g), torch.randint(104, 220, (n_edges - n_edges // 2,), generator=g)])
+    ei = torch.stack([src, dst]).cuda()
+    gs = GraphStructure(ei, batch, n)
+    h, u, pos, var, gout = r(n, 128), r(n, tw), r(n), r(n, nv), r(n, 128)
+    k1, k3 = 256 + tw + 1 + nv, 256 + nv
+    def params():
+        return [r(128, k1) / k1 ** 0.5, r(128) * 0.1, r(128, 128) / 128 ** 0.5, r(128) * 0.1,
+                r(128, k3) / k3 ** 0.5, r(128) * 0.1, r(128, 128) / 128 ** 0.5, r(128) * 0.1]
+    ps = params() + (params() if form == 'gated' else [])
+    dh, grads = A.layer_backward_native(gout, h, u, pos, var, gs, ps, form != 'residual', form == 'gated', eps)
+    h64 = h.double().requires_grad_(True)
+    p64 = [q.double().requires_grad_(True) for q in ps]
+    s64, d64 = gs.col_long, gs.tgt_long
+    args = (u.double(), pos.double(), var.double(), s64, d64, batch, len(sizes))
+    if form == 'gated':
+        tau = torch.sigmoid(A.layer_reference(h64, *args, p64[8:], True, eps))
+        out = (1 - tau) * h64 + tau * A._swish(A.layer_reference(h64, *args, p64[:8], True, eps))
+    else:
+        out = A.layer_reference(h64, *args, p64, form == 'lin', eps)
+    out.backward(gout.double())
+    multi = ((batch != 0) & (batch != 4))[:, None]       # 1- and 2-node graphs: InstanceNorm's derivative is ill-conditioned
+    scale = max(q.grad.abs().max().item() for q in p64)
+    assert ((dh.double() - h64.grad) * multi).abs().max().item() < 2e-4 * max(h64.grad.abs().max().item(), 1.0)
+    for i, (got, ref) in enumerate(zip(grads, p64)):
+        assert got.shape == ref.shape
+        assert (got.double() - ref.grad).abs().max().item() < 1e-4 * ref.grad.abs().max().item() + 2e-5 * scale, (form, n_edges, i)

@@ -53,6 +53,8 @@ def test_argument_errors_are_reported_not_thrown(mp):
     assert L.msmp_decoder2d_f32(None, None, 10, 25, None, None, None, None, 0.016, None, None) == -1
     assert L.msmp_packed_mlp2_floats(28) == 32 + 256 + (1 + 4) * 4096 and L.msmp_packed_mlp2_floats(129) == -1
     assert L.msmp_mlp2_input_stride(28) == 32 and L.msmp_mlp2_input_stride(59) == 64
+    assert L.msmp_mp_layer_bwd_f32(*([None] * 9), 10, 20, 1, 25, 2, None, None, 1, 1e-5, None, None, None, None, 0, None) == -1
+    assert L.msmp_mp_layer_bwd_workspace_bytes(0, 5, 25, 2, 1) == 0 and L.msmp_mp_layer_bwd_workspace_bytes(100, 588, 25, 2, 1) > 0
     # knobs: known keys are accepted, unknown ones rejected with a message
     for key in (b'split', b'edge_nb', b'edge_occ', b'edge_ws', b'edge_xcd', b'tail', b'pair', b'lem', b'lem_nodes'):
         assert L.msmp_tune(key, {b'split': 1, b'edge_occ': 2, b'tail': 1, b'lem': 3, b'lem_nodes': 1}.get(key, 0)) == 0, key
