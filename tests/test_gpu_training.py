@@ -219,28 +219,31 @@ def test_backward_glue_kernels_match_float64_autograd(mp):
 
 
 def test_explicit_backward_equals_autograd_recompute(mp):
-    """The explicit layer backward (library GEMMs + glue kernels) against torch.autograd over the PyTorch restatement of
-    the same layer, both fp32 on the GPU, for the three layer forms (residual-Swish, Lin, gated pair)."""
+    """The three backward paths of a layer -- msmp_mp_layer_bwd_f32 (2, the default), the same algorithm orchestrated from Python
+    with library GEMMs (1), torch.autograd over the PyTorch restatement (0) -- all fp32 on the GPU, for the three layer forms
+    (residual-Swish, Lin, gated pair)."""
     from msmp_pde_amd import autograd as A
     from msmp_pde_amd.synthetic import make_case
     c = make_case('E2', 5, seed=3, device='cuda', dtype=torch.float32)
+    assert A.EXPLICIT_BACKWARD == 2
     for name in ('MP-PDE', 'Gated'):
-        grads = []
-        for explicit in (True, False):
-            A.EXPLICIT_BACKWARD = explicit
+        grads = {}
+        for path in (2, 1, 0):
+            A.EXPLICIT_BACKWARD = path
             try:
                 torch.manual_seed(1)
                 model = mp.MODEL_NAMES[name](c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=2).cuda()
                 data, labels = c.creator.create_data(c.u_super, [60] * 5)
                 graph = c.creator.create_graph(data, labels, c.x, c.variables, [60] * 5)
                 torch.sqrt(((model(graph) - graph.y) ** 2).sum()).backward()
-                grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+                grads[path] = {k: p.grad.clone() for k, p in model.named_parameters()}
             finally:
-                A.EXPLICIT_BACKWARD = True
-        scale = max(v.abs().max().item() for v in grads[1].values())
-        for k in grads[0]:
-            err = (grads[0][k] - grads[1][k]).abs().max().item()
-            assert err < 1e-4 * grads[1][k].abs().max().item() + 1e-5 * scale, (name, k, err)
+                A.EXPLICIT_BACKWARD = 2
+        scale = max(v.abs().max().item() for v in grads[0].values())
+        for path in (2, 1):
+            for k in grads[0]:
+                err = (grads[path][k] - grads[0][k]).abs().max().item()
+                assert err < 1e-4 * grads[0][k].abs().max().item() + 1e-5 * scale, (name, path, k, err)
 
 
 def test_grad_weights_kernel_shapes_and_strides(mp):
