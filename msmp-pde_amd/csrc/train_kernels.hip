@@ -508,10 +508,10 @@ static void carve(float*& p, long n, long e, int ld_e, int ld_n, HeadBuf& b) {
 #define RC(call) do { const int rc_ = (call); if (rc_) return rc_; } while (0)
 
 // upd = W4 Swish(W3 [h, mean_j Swish(W2 Swish(W1 cat_e + b1) + b2), vars] + b3) + b4, keeping the pre-activations
-static int head_recompute(const BwdCtx& c, Blas& bl, const float* const* p, HeadBuf& b) {
+static int head_recompute(const BwdCtx& c, Blas& bl, const float* const* p, HeadBuf& b, bool build_cat_e) {
     const long n = c.n, e = c.e;
     if (e) {
-        RC(msmp_edge_concat_f32(c.h, c.u, c.pos, c.vars, c.tgt, c.col, e, c.tw, c.nv, c.ld_e, b.cat_e, c.st));
+        if (build_cat_e) RC(msmp_edge_concat_f32(c.h, c.u, c.pos, c.vars, c.tgt, c.col, e, c.tw, c.nv, c.ld_e, b.cat_e, c.st));
         BLAS_OK(gemm_nt(bl, (int)e, H, c.kmsg, b.cat_e, c.ld_e, p[0], c.kmsg, b.a1, H), "message_net_1");
         hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.a1, p[1], b.m1, e * 32);
         BLAS_OK(gemm_nt(bl, (int)e, H, H, b.m1, H, p[2], H, b.a2, H), "message_net_2");
@@ -624,9 +624,10 @@ extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, cons
     const long n4 = c.n * 32;
     GwJobs jobs;
 
-    RC(head_recompute(c, bl, params_main, bm));
+    RC(head_recompute(c, bl, params_main, bm, true));
     if (gated) {
-        RC(head_recompute(c, bl, params_gate, bg));
+        bg.cat_e = bm.cat_e;                      // both heads read the same per-edge input
+        RC(head_recompute(c, bl, params_gate, bg, false));
         RC(msmp_gate_blend_bwd_f32(grad_out, h, bg.upd, bm.upd, graph_ptr, n_graphs, eps, bg.dupd, bm.dupd, dh_out, stream));
         RC(head_backward(c, bl, params_main, bm, dh_out, grads_main, jobs));
         RC(head_backward(c, bl, params_gate, bg, dh_out, grads_gate, jobs));
