@@ -105,6 +105,30 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+# ---- freshness of the packed-weight caches ------------------------------------------------------------------------------
+# The kernel-layout weight blobs are cached per module and re-packed when a parameter changed.  `Tensor._version` alone does
+# not see every change: fused optimizers (torch.optim.AdamW(fused=True): torch._fused_adamw_) update the parameters without
+# bumping it, and so do edits through `.data`.  Every cache key therefore also carries PARAM_EPOCH, which a process-wide
+# optimizer hook advances after ANY optimizer.step(); `invalidate_packed_weights()` does the same by hand for exotic in-place
+# edits (p.data.copy_(...) and the like).
+PARAM_EPOCH = [0]
+
+
+def invalidate_packed_weights(*_args, **_kwargs):
+    PARAM_EPOCH[0] += 1
+
+
+def _install_optimizer_hook():
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        register_optimizer_step_post_hook(invalidate_packed_weights)
+    except Exception as exc:          # very old torch: fall back to version keys only, loudly
+        import warnings
+        warnings.warn(f'msmp_pde_amd: no global optimizer hook ({exc}); call invalidate_packed_weights() after fused optimizer steps')
+
+
+_install_optimizer_hook()
+
 _raw_stream = None
 
 

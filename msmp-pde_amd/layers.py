@@ -72,7 +72,7 @@ class _MPLayerBase(nn.Module):
     def packed(self):
         """Kernel-layout weight blob (msmp_pack_layer_f32), re-packed only when a parameter changed."""
         ps = self._params8()
-        key = (ps[0].data_ptr(), ps[7].data_ptr(), ps[0].dtype) + tuple(p._version for p in ps)
+        key = (_lib.PARAM_EPOCH[0], ps[0].data_ptr(), ps[7].data_ptr(), ps[0].dtype) + tuple(p._version for p in ps)
         if key != self._packed_key:
             dev = ps[0].device
             if dev.type != 'cuda' or any(p.device != dev for p in ps):

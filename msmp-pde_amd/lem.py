@@ -14,7 +14,7 @@ import math
 import torch
 from torch import nn
 
-from ._lib import lib, check, ptr, current_stream, MSMP_ERR_UNSUPPORTED
+from ._lib import lib, check, ptr, current_stream, MSMP_ERR_UNSUPPORTED, PARAM_EPOCH
 
 
 class LEMcuda(nn.Module):
@@ -131,7 +131,7 @@ class LEM(nn.Module):
         ps = [self.rnn.weights, self.rnn.weights_lin_z, self.rnn.bias, self.rnn.bias_lin_z]
         if mlp is not None:
             ps += [mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias]
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        key = (PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
         if key != self._packed_key:
             L = lib()
             blob = torch.empty(L.msmp_packed_lem_floats(), dtype=torch.float32, device=ps[0].device)

@@ -20,7 +20,7 @@ dtype is float32; the result is returned in the dtype of `data.x`.
 import torch
 from torch import nn
 
-from ._lib import lib, check, ptr, current_stream
+from ._lib import lib, check, ptr, current_stream, PARAM_EPOCH
 from .graph import structure_of
 from .layers import GNN_Layer, GNN_LayerLin, Swish, mp_layer
 from .lem import LEM
@@ -167,7 +167,7 @@ class _SolverBase(nn.Module):
         """embedding_mlp as one HIP kernel (msmp_mlp2_swish_f32); the packed weights are cached per parameter version."""
         lin1, lin2 = self.embedding_mlp[0], self.embedding_mlp[2]
         ps = (lin1.weight, lin1.bias, lin2.weight, lin2.bias)
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        key = (PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
         L = lib()
         k_in = lin1.in_features
         if getattr(self, '_embed_key', None) != key:

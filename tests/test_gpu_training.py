@@ -314,3 +314,44 @@ def test_layer_backward_entry_vs_float64_autograd(mp, form, n_edges):
     for i, (got, ref) in enumerate(zip(grads, p64)):
         assert got.shape == ref.shape
         assert (got.double() - ref.grad).abs().max().item() < 1e-4 * ref.grad.abs().max().item() + 2e-5 * scale, (form, n_edges, i)
+
+
+@pytest.mark.parametrize('name', ['MSMP-PDE', 'MP-PDE'])
+def test_packed_weights_follow_fused_optimizer_and_data_edits(mp, name):
+    """The kernel-layout weight caches must follow every parameter update.  torch.optim.AdamW(fused=True) updates parameters
+    WITHOUT bumping Tensor._version (found by a training soak: the forward kept using the packed weights of step 0), so the cache
+    keys also carry an epoch that a process-wide optimizer-step hook advances; edits through `.data` need
+    invalidate_packed_weights().  Checked against a fresh model loaded with the same state_dict, in train and eval mode."""
+    from msmp_pde_amd import train as T
+    from msmp_pde_amd.synthetic import make_case
+    torch.manual_seed(1)
+    c = make_case('E2', 4, seed=2, device='cuda', dtype=torch.float32)
+    cls = mp.MODEL_NAMES[name]
+    model = cls(c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=2).cuda().train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, fused=True)
+    steps = [60] * 4
+    data, labels = c.creator.create_data(c.u_super, steps)
+    graph = c.creator.create_graph(data, labels, c.x, c.variables, steps)
+
+    def fresh_outputs():
+        fresh = cls(c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=2).cuda()
+        fresh.load_state_dict(model.state_dict())
+        with torch.no_grad():
+            return fresh.train()(graph), fresh.eval()(graph)
+
+    with torch.no_grad():
+        before = model(graph)
+    for _ in range(3):
+        T.training_step(model, c.creator, c.u_super, c.x, c.variables, steps, 1, opt)
+    want_train, want_eval = fresh_outputs()
+    with torch.no_grad():
+        assert (model(graph) - before).abs().max().item() > 1e-3          # the weights did move
+        assert torch.equal(model.train()(graph), want_train)
+        assert torch.equal(model.eval()(graph), want_eval)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.data.mul_(1.01)                                               # invisible to Tensor._version
+    mp.invalidate_packed_weights()
+    want_train, _ = fresh_outputs()
+    with torch.no_grad():
+        assert torch.equal(model.train()(graph), want_train)
