@@ -246,3 +246,41 @@ def test_large_neighbourhood_stress_vs_oracle(mp, neighbors):
     err = np.abs(out.double().cpu().numpy() - ref).max()
     print(f'n={neighbors}: E/graph {ei_ref.shape[1] // 6}, max in-degree {deg.max()}, max|hip - oracle| = {err:.3e}, fp32 floor {floor:.3e}')
     assert err < max(TOL, 8 * floor), (err, floor)
+
+
+@pytest.mark.parametrize('nx', [40, 200])
+def test_other_grid_resolutions_vs_oracle(mp, nx):
+    """Grids other than nx = 100 (the reference also runs base resolutions 250 x 50 / 40 and super-resolved 200): graphs of 200
+    nodes exceed the 128-node limit of the fused node tail and take the piecewise kernels (node_update per head, generic
+    InstanceNorm / gate blend); 40-node graphs pack several graphs into every tile.  Forward within the 1e-5 bar, rollout state
+    update, and the parameter gradients against float64 autograd through the oracle."""
+    from oracle import msmp_oracle_torch as OT
+    from msmp_pde_amd.synthetic import make_case
+    from types import SimpleNamespace
+    torch.manual_seed(8)
+    c = make_case('E2', 5, seed=6, device='cuda', nx=nx, dtype=torch.float64)
+    steps = [50] * 5
+    data, labels = c.creator.create_data(c.u_super, steps)
+    graph = c.creator.create_graph(data, labels, c.x, c.variables, steps)
+    kind = 'MP_PDE_SolverLEMLinGated'
+    model = getattr(mp, kind)(c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=2).cuda()
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    g = SimpleNamespace(**{k: v.detach().cpu().numpy() for k, v in graph.__dict__.items() if torch.is_tensor(v)})
+    ref = O.solver_forward(kind, sd, g, c.pde, TW, c.eqv, 2)
+    floor = np.abs(O.solver_forward(kind, sd, g, c.pde, TW, c.eqv, 2, dtype=np.float32).astype(np.float64) - ref).max()
+    with torch.no_grad():
+        out = model.eval()(graph)
+    err = np.abs(out.double().cpu().numpy() - ref).max()
+    print(f'nx={nx}: max|hip - oracle| = {err:.3e}, fp32 floor {floor:.3e}')
+    assert err < max(TOL, 8 * floor), (err, floor)
+    # gradients on the same batch
+    model.train()
+    loss = torch.sqrt(((model(graph) - graph.y) ** 2).sum())
+    loss.backward()
+    sd64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    ref_loss = torch.sqrt(((OT.solver_forward(kind, sd64, g, c.pde, TW, c.eqv, 2, as_numpy=False) - torch.tensor(g.y).double()) ** 2).sum())
+    ref_loss.backward()
+    scale = max(v.grad.abs().max().item() for v in sd64.values())
+    for name, p in model.named_parameters():
+        e = (p.grad.double().cpu() - sd64[name].grad).abs().max().item()
+        assert e < 2e-3 * sd64[name].grad.abs().max().item() + 1e-4 * scale, (name, e)
