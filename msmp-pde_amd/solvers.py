@@ -64,10 +64,25 @@ class _OutEdgeMean(torch.autograd.Function):
         return (g / deg[:, None])[ctx.gs.col_long], None
 
 
+class LSTM(nn.Module):
+    """experiments/models_gnn.py:758-767: torch.nn.LSTM(ninp, nhid), returns output[-1].  Parameter names as the reference's
+    (`rnn.weight_ih_l0` ...)."""
+
+    def __init__(self, ninp, nhid):
+        super().__init__()
+        self.ninp, self.nhid = ninp, nhid
+        self.rnn = nn.LSTM(ninp, nhid)
+
+    def forward(self, inputs):
+        output, _ = self.rnn(inputs.contiguous())
+        return output[-1]
+
+
 class _SolverBase(nn.Module):
     TWO_D = False
     GATED = False
     LEM_ENCODER = False
+    LSTM_ENCODER = False    # the LSTM ablations: torch.nn.LSTM (MIOpen) in place of the LEM, everything after it unchanged
     G2 = False
     RETURN_DIFF = False     # MSSMP_PDE_Solver_sub: forward returns the decoder output, not the Euler update
     LAYER = GNN_Layer
@@ -92,7 +107,11 @@ class _SolverBase(nn.Module):
         if self.GATED or self.G2:
             self.gnn_layers_gate = nn.ModuleList(mk() for _ in range(hidden_layer))
             self.swish = Swish()
-        if self.LEM_ENCODER:
+        if self.LSTM_ENCODER:
+            self.embedding_lstm = LSTM(2 + len(eq_variables) + comps, hidden_features)
+            self.lstmoutput_mlp = nn.Sequential(_lin(hidden_features, hidden_features), Swish(),
+                                                _lin(hidden_features, hidden_features), Swish())
+        elif self.LEM_ENCODER:
             self.embedding_lem = LEM(2 + len(eq_variables) + comps, hidden_features)
             self.lemoutput_mlp = nn.Sequential(_lin(hidden_features, hidden_features), Swish(),
                                                _lin(hidden_features, hidden_features), Swish())
@@ -131,6 +150,8 @@ class _SolverBase(nn.Module):
         return torch.cat([c.to(pos_t.dtype) for c in cols], -1)
 
     def _encode(self, u, pos_x, pos_t, variables, dt):
+        if self.LSTM_ENCODER:           # models_gnn.py:880-887 / 1042-1052; models_gnn2D.py:752-758 / 894-900
+            return self.lstmoutput_mlp(self.embedding_lstm(self._step_inputs(u, pos_x, pos_t, variables, dt).permute(1, 0, 2)))
         if not self.LEM_ENCODER:        # models_gnn.py:269-270
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.embedding_mlp.parameters()):
                 return self.embedding_mlp(torch.cat((u, pos_x, variables), -1))      # differentiable PyTorch path
@@ -142,18 +163,22 @@ class _SolverBase(nn.Module):
             h = self.embedding_lem.encode_nodes(u, pos_x, pos_t, variables, dt, self.TWO_D, self.lemoutput_mlp)
             if h is not None:
                 return h
-        if self.TWO_D:                  # models_gnn2D.py:421-436
-            ts = dt.view(1, tw) + pos_t
-            lem_in = torch.stack([pos_x.expand(n, tw), u[:, :tw], u[:, tw:], ts], -1)       # [N, tw, 4]
-            lem_in = torch.cat((lem_in, variables[:, None, 1:].expand(n, tw, variables.shape[1] - 1)), -1)
-        else:                           # models_gnn.py:1356-1363
-            t_len = u.shape[1]
-            lem_in = torch.cat((pos_x[:, None, :].expand(n, t_len, 1), u[:, :, None],
-                                variables[:, None, :].expand(n, t_len, variables.shape[1])), -1)
+        lem_in = self._step_inputs(u, pos_x, pos_t, variables, dt)
         if grad:
             h = self.embedding_lem.forward_nodes(lem_in)       # HIP training kernels (recurrence forward + BPTT)
             return self.lemoutput_mlp(h)
         return self.embedding_lem.encode(lem_in, self.lemoutput_mlp)       # fused HIP kernel (recurrence + MLP)
+
+    def _step_inputs(self, u, pos_x, pos_t, variables, dt):
+        """The recurrent encoder's per-step inputs, node-major [N, T, ninp]."""
+        tw, n = self.time_window, u.shape[0]
+        if self.TWO_D:                  # models_gnn2D.py:421-436
+            ts = dt.view(1, tw) + pos_t
+            x = torch.stack([pos_x.expand(n, tw), u[:, :tw], u[:, tw:], ts], -1)       # [N, tw, 4]
+            return torch.cat((x, variables[:, None, 1:].expand(n, tw, variables.shape[1] - 1)), -1)
+        t_len = u.shape[1]              # models_gnn.py:1356-1363
+        return torch.cat((pos_x[:, None, :].expand(n, t_len, 1), u[:, :, None],
+                          variables[:, None, :].expand(n, t_len, variables.shape[1])), -1)
 
     def _g2_pair(self, h, u, pos_x, variables, gs, i):
         """models_gnn2D.py:606-611 (gradient gating): tau = tanh(mean over the out-edges j -> i of node j of |t_j - t_i|^2) with
@@ -301,6 +326,26 @@ class MP_PDE_Solver2DLEMLinG2(_SolverBase):
     TWO_D, LEM_ENCODER, G2, LAYER = True, True, True, GNN_LayerLin
 
 
+class MP_PDE_SolverLSTMLin(_SolverBase):
+    """experiments/models_gnn.py:770-907 (train.py name 'LSTM')."""
+    LSTM_ENCODER = True
+
+
+class MP_PDE_SolverLSTMLinGated(_SolverBase):
+    """experiments/models_gnn.py:909-1065 (train.py name 'LSTMGated')."""
+    GATED, LSTM_ENCODER, LAYER = True, True, GNN_LayerLin
+
+
+class MP_PDE_Solver2DLSTMLin(_SolverBase):
+    """experiments/models_gnn2D.py:782-918 (train.py name 'LSTM2D')."""
+    TWO_D, LSTM_ENCODER = True, True
+
+
+class MP_PDE_Solver2DLSTMLinGated(_SolverBase):
+    """experiments/models_gnn2D.py:622-780 (train.py name 'LSTMGated2D')."""
+    TWO_D, GATED, LSTM_ENCODER, LAYER = True, True, True, GNN_LayerLin
+
+
 class MSSMP_PDE_Solver_sub(_SolverBase):
     """experiments/models_gnn.py:1525-1682: the MSMP-PDE network whose forward returns the decoder output `diff`."""
     GATED, LEM_ENCODER, RETURN_DIFF, LAYER = True, True, True, GNN_LayerLin
@@ -333,4 +378,6 @@ MODEL_NAMES = {   # experiments/train.py:34-183 getModel names -> class
     'MP-PDE2D': MP_PDE_Solver2D, 'Gated2D': MP_PDE_Solver2DGated, 'MSMP-PDE2D': MP_PDE_Solver2DLEMLinGated,
     'LEM': MP_PDE_SolverLEMLin, 'LEM2D': MP_PDE_Solver2DLEMLin, 'MSG2-PDE2D': MP_PDE_Solver2DLEMLinG2,
     'MSSMP-PDE': MSSMP_PDE_Solver,
+    'LSTM': MP_PDE_SolverLSTMLin, 'LSTMGated': MP_PDE_SolverLSTMLinGated, 'LSTM2D': MP_PDE_Solver2DLSTMLin,
+    'LSTMGated2D': MP_PDE_Solver2DLSTMLinGated,
 }

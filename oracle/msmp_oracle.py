@@ -145,12 +145,27 @@ def lem_forward(inputs, weights, weights_lin_z, bias, bias_lin_z, dt=1.0):
     return y
 
 
+def lstm_forward(inputs, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.LSTM(ninp, nhid) with zero initial state, output[-1] (experiments/models_gnn.py:758-767): gates in the order
+    i, f, g, o;  c <- s(f) c + s(i) tanh(g);  h <- s(o) tanh(c).  inputs [T, N, ninp]."""
+    t_len, n, _ = inputs.shape
+    nh = w_hh.shape[1]
+    h = np.zeros((n, nh), dtype=inputs.dtype)
+    c = np.zeros((n, nh), dtype=inputs.dtype)
+    for t in range(t_len):
+        g = inputs[t] @ w_ih.T + b_ih + h @ w_hh.T + b_hh
+        c = sigmoid(g[:, nh:2 * nh]) * c + sigmoid(g[:, :nh]) * np.tanh(g[:, 2 * nh:3 * nh])
+        h = sigmoid(g[:, 3 * nh:]) * np.tanh(c)
+    return h
+
+
 # --------------------------------------------------------------------------------------------
 # solver forward passes
 # --------------------------------------------------------------------------------------------
-KINDS_1D = ('MP_PDE_Solver', 'MP_PDE_SolverGated', 'MP_PDE_SolverLEMLinGated', 'MP_PDE_SolverLEMLin', 'MSSMP_PDE_Solver')
+KINDS_1D = ('MP_PDE_Solver', 'MP_PDE_SolverGated', 'MP_PDE_SolverLEMLinGated', 'MP_PDE_SolverLEMLin', 'MSSMP_PDE_Solver',
+            'MP_PDE_SolverLSTMLin', 'MP_PDE_SolverLSTMLinGated')
 KINDS_2D = ('MP_PDE_Solver2D', 'MP_PDE_Solver2DGated', 'MP_PDE_Solver2DLEMLinGated', 'MP_PDE_Solver2DLEMLin',
-            'MP_PDE_Solver2DLEMLinG2')
+            'MP_PDE_Solver2DLEMLinG2', 'MP_PDE_Solver2DLSTMLin', 'MP_PDE_Solver2DLSTMLinGated')
 
 _DECODER = {  # time_window -> (k1, stride1, k2); experiments/models_gnn.py:210-224, models_gnn2D.py:79-88
     20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}
@@ -215,7 +230,7 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
 
     gated = 'Gated' in kind
     g2 = kind.endswith('G2')
-    if 'LEM' in kind:
+    if 'LEM' in kind or 'LSTM' in kind:
         if two_d:   # models_gnn2D.py:421-436
             ts = dt[None, :] + pos_t
             steps = [np.concatenate((pos_x, u[:, t:t + 1], u[:, t + tw:t + tw + 1], ts[:, t:t + 1],
@@ -223,10 +238,16 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
         else:       # models_gnn.py:1356-1363
             steps = [np.concatenate((pos_x, u[:, t:t + 1], variables), axis=-1) for t in range(u.shape[1])]
         lem_in = np.stack(steps, axis=0)
-        h = lem_forward(lem_in, sd['embedding_lem.rnn.weights'], sd['embedding_lem.rnn.weights_lin_z'],
-                        sd['embedding_lem.rnn.bias'], sd['embedding_lem.rnn.bias_lin_z'], 1.0)
-        h = swish(linear(h, sd['lemoutput_mlp.0.weight'], sd['lemoutput_mlp.0.bias']))
-        h = swish(linear(h, sd['lemoutput_mlp.2.weight'], sd['lemoutput_mlp.2.bias']))
+        if 'LSTM' in kind:      # the LSTM ablations (models_gnn.py:770-1065, models_gnn2D.py:622-918): same inputs, nn.LSTM encoder
+            r = 'embedding_lstm.rnn.'
+            h = lstm_forward(lem_in, sd[r + 'weight_ih_l0'], sd[r + 'weight_hh_l0'], sd[r + 'bias_ih_l0'], sd[r + 'bias_hh_l0'])
+            mlp = 'lstmoutput_mlp'
+        else:
+            h = lem_forward(lem_in, sd['embedding_lem.rnn.weights'], sd['embedding_lem.rnn.weights_lin_z'],
+                            sd['embedding_lem.rnn.bias'], sd['embedding_lem.rnn.bias_lin_z'], 1.0)
+            mlp = 'lemoutput_mlp'
+        h = swish(linear(h, sd[mlp + '.0.weight'], sd[mlp + '.0.bias']))
+        h = swish(linear(h, sd[mlp + '.2.weight'], sd[mlp + '.2.bias']))
     else:
         node_input = np.concatenate((u, pos_x, variables), axis=-1)
         h = swish(linear(node_input, sd['embedding_mlp.0.weight'], sd['embedding_mlp.0.bias']))

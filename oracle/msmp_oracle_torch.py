@@ -79,17 +79,29 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
     b = int(batch.max()) + 1
     pos_x, pos_t, variables = (t64(a) for a in O.build_variables(kind, data, pde, eq_variables))
     dt = torch.cumsum(torch.ones(tw, dtype=torch.float64) * pde.dt, 0)
-    if 'LEM' in kind:
+    if 'LEM' in kind or 'LSTM' in kind:
         if two_d:
             ts = dt[None, :] + pos_t
             steps = [torch.cat((pos_x, u[:, t:t + 1], u[:, t + tw:t + tw + 1], ts[:, t:t + 1], variables[:, 1:]), -1)
                      for t in range(tw)]
         else:
             steps = [torch.cat((pos_x, u[:, t:t + 1], variables), -1) for t in range(u.shape[1])]
-        h = lem_forward(torch.stack(steps, 0), sd['embedding_lem.rnn.weights'], sd['embedding_lem.rnn.weights_lin_z'],
-                        sd['embedding_lem.rnn.bias'], sd['embedding_lem.rnn.bias_lin_z'], 1.0)
-        h = swish(F.linear(h, sd['lemoutput_mlp.0.weight'], sd['lemoutput_mlp.0.bias']))
-        h = swish(F.linear(h, sd['lemoutput_mlp.2.weight'], sd['lemoutput_mlp.2.bias']))
+        if 'LSTM' in kind:
+            r = 'embedding_lstm.rnn.'
+            x, nh = torch.stack(steps, 0), sd[r + 'weight_hh_l0'].shape[1]
+            h = torch.zeros(x.shape[1], nh, dtype=x.dtype)
+            c = torch.zeros_like(h)
+            for t in range(x.shape[0]):
+                g = F.linear(x[t], sd[r + 'weight_ih_l0'], sd[r + 'bias_ih_l0']) + F.linear(h, sd[r + 'weight_hh_l0'], sd[r + 'bias_hh_l0'])
+                c = torch.sigmoid(g[:, nh:2 * nh]) * c + torch.sigmoid(g[:, :nh]) * torch.tanh(g[:, 2 * nh:3 * nh])
+                h = torch.sigmoid(g[:, 3 * nh:]) * torch.tanh(c)
+            mlp = 'lstmoutput_mlp'
+        else:
+            h = lem_forward(torch.stack(steps, 0), sd['embedding_lem.rnn.weights'], sd['embedding_lem.rnn.weights_lin_z'],
+                            sd['embedding_lem.rnn.bias'], sd['embedding_lem.rnn.bias_lin_z'], 1.0)
+            mlp = 'lemoutput_mlp'
+        h = swish(F.linear(h, sd[mlp + '.0.weight'], sd[mlp + '.0.bias']))
+        h = swish(F.linear(h, sd[mlp + '.2.weight'], sd[mlp + '.2.bias']))
     else:
         h = swish(F.linear(torch.cat((u, pos_x, variables), -1), sd['embedding_mlp.0.weight'], sd['embedding_mlp.0.bias']))
         h = swish(F.linear(h, sd['embedding_mlp.2.weight'], sd['embedding_mlp.2.bias']))
