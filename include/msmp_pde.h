@@ -261,8 +261,10 @@ int msmp_lem_encoder_nodes_f32(const float* u, const float* pos_x, const float* 
  * saved [6][N][T][128] floats (msmp_lem_saved_floats) = dt*sigmoid(g2), tanh(g3), dt*sigmoid(g1), tanh(lin), y_t, z_t.
  * xin / packed as for msmp_lem_encoder_f32; y_out [N,128] = all_y[-1]. */
 int64_t msmp_lem_saved_floats(int64_t n_nodes, int t_len);
+/* y0 / z0 [N,128]: the initial states (LEMcuda.forward's `states`, :325-332; both NULL = zeros); z_out [N,128] = all_z[-1] (or
+ * NULL); saved may be NULL when no backward follows (the state-carrying LEMS of the `Save` variants under no_grad, :345-362). */
 int msmp_lem_train_fwd_f32(const float* xin, int64_t n_nodes, int t_len, int ninp, float dt, const float* packed,
-                           float* saved, float* y_out, msmp_stream_t stream);
+                           const float* y0, const float* z0, float* saved, float* y_out, float* z_out, msmp_stream_t stream);
 /* The transposed recurrent blocks of weights / weights_lin_z for the backward kernel (16 chunks of [128][32]). */
 int64_t msmp_packed_lem_bwd_floats(void);
 int msmp_pack_lem_bwd_f32(const float* weights, const float* weights_lin_z, int ninp, float* packed_out,
@@ -271,9 +273,10 @@ int msmp_pack_lem_bwd_f32(const float* weights, const float* weights_lin_z, int 
  * dg_out [N][T][512] = dL/d(pre-activations) per node and step, columns (g1 | g2 | g3 | lin) in the row order of
  * `weights` then `weights_lin_z`.  The parameter gradients are GEMMs of it over the N*T rows:
  *   d weights = dg[:, :384]^T [y_{t-1} | x_t],  d weights_lin_z = dg[:, 384:]^T [z_t | x_t],  d bias* = column sums
- * (y, z = planes 4, 5 of `saved`).  Like the reference, no gradient of the step inputs is produced (:300-302). */
-int msmp_lem_train_bwd_f32(const float* grad_y, const float* saved, int64_t n_nodes, int t_len, float dt,
-                           const float* packed_bwd, float* dg_out, msmp_stream_t stream);
+ * (y, z = planes 4, 5 of `saved`; y_{-1} = y0, the forward's initial state, or 0).  Like the reference's use of it, no gradient
+ * of the step inputs is produced (:300-302), nor of the initial states (they are carried constants, :350-353). */
+int msmp_lem_train_bwd_f32(const float* grad_y, const float* saved, const float* y0, const float* z0, int64_t n_nodes, int t_len,
+                           float dt, const float* packed_bwd, float* dg_out, msmp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training backward of a message-passing layer: the non-GEMM pieces.  The host layer

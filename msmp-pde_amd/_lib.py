@@ -46,10 +46,10 @@ SIGNATURES = {
     'msmp_node_tail_f32': (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     'msmp_lem_encoder_nodes_f32': (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     'msmp_lem_saved_floats': (c_int64, [c_int64, c_int]),
-    'msmp_lem_train_fwd_f32': (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'msmp_lem_train_fwd_f32': (c_int, [c_void_p, c_int64, c_int, c_int, c_float] + [c_void_p] * 7),
     'msmp_packed_lem_bwd_floats': (c_int64, []),
     'msmp_pack_lem_bwd_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    'msmp_lem_train_bwd_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    'msmp_lem_train_bwd_f32': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'msmp_edge_concat_f32': (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     'msmp_mean_bwd_dswish_f32': (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p]),
     'msmp_instance_norm_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),

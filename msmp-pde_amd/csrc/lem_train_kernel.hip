@@ -37,8 +37,11 @@ struct LemTrainArgs {
     const float* rec;    // 16 chunks (g2, g3, g1, lin)
     const float* bias;   // [512]
     const float* wx;     // input-column fragments
-    float* saved;        // [6][N][T][128]
+    float* saved;        // [6][N][T][128], or NULL (no backward will follow: inference with carried states)
     float* out;          // [N,128] = y_T
+    const float* y0;     // [N,128] initial states, or NULL = zeros (LEMcuda.forward's `states`, models_gnn.py:325-332)
+    const float* z0;
+    float* z_out;        // [N,128] = z_T, or NULL
 };
 
 // one tile of a node row <-> accumulator registers: register 4q+m of tile T is channel 32T + 8q + 4hh + m
@@ -126,6 +129,9 @@ __global__ __launch_bounds__(256) void lem_train_fwd_kernel(LemTrainArgs a) {
     f32x16 y, z, g, acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { y[r] = 0.f; z[r] = 0.f; }
+    if (a.y0) tile_load(a.y0 + (size_t)nc * H + 4 * hh, ct, y);
+    if (a.z0) tile_load(a.z0 + (size_t)nc * H + 4 * hh, ct, z);
+    const bool save = live && a.saved != nullptr;
     publish_tile(xs, ct, c, hh, y);
 
     WStage ws;
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(256) void lem_train_fwd_kernel(LemTrainArgs a) {
         LEM_TRAIN_GROUP(a.rec, g, 0, a.rec + 4 * CHUNK_FLOATS)
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] = a.dt * sigmoidf_(g[r]);
-        if (live) tile_store(st + SV_A2 * plane, ct, g);
+        if (save) tile_store(st + SV_A2 * plane, ct, g);
         tile_init<NS>(a, 2, ct, lane, hh, x, acc);                    // g3 -> c, z'
         LEM_TRAIN_GROUP(a.rec, acc, 4, a.rec + 8 * CHUNK_FLOATS)
 #pragma unroll
@@ -151,12 +157,12 @@ __global__ __launch_bounds__(256) void lem_train_fwd_kernel(LemTrainArgs a) {
             acc[r] = tanhf_(acc[r]);
             z[r] = (1.0f - g[r]) * z[r] + g[r] * acc[r];
         }
-        if (live) { tile_store(st + SV_C * plane, ct, acc); tile_store(st + SV_Z * plane, ct, z); }
+        if (save) { tile_store(st + SV_C * plane, ct, acc); tile_store(st + SV_Z * plane, ct, z); }
         tile_init<NS>(a, 0, ct, lane, hh, x, g);                      // g1 -> a1
         LEM_TRAIN_GROUP(a.rec, g, 8, a.rec + 12 * CHUNK_FLOATS)
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] = a.dt * sigmoidf_(g[r]);
-        if (live) tile_store(st + SV_A1 * plane, ct, g);
+        if (save) tile_store(st + SV_A1 * plane, ct, g);
         publish_tile(xs, ct, c, hh, z);                               // every wave is past the barrier after its last read of y
         __syncthreads();
         tile_init<NS>(a, 3, ct, lane, hh, x, acc);                    // lin -> d, y'        (xs = z')
@@ -166,11 +172,12 @@ __global__ __launch_bounds__(256) void lem_train_fwd_kernel(LemTrainArgs a) {
             acc[r] = tanhf_(acc[r]);
             y[r] = (1.0f - g[r]) * y[r] + g[r] * acc[r];
         }
-        if (live) { tile_store(st + SV_D * plane, ct, acc); tile_store(st + SV_Y * plane, ct, y); }
+        if (save) { tile_store(st + SV_D * plane, ct, acc); tile_store(st + SV_Y * plane, ct, y); }
         publish_tile(xs, ct, c, hh, y);
         __syncthreads();
     }
     if (live) tile_store(a.out + (size_t)n * H + 4 * hh, ct, y);
+    if (live && a.z_out) tile_store(a.z_out + (size_t)n * H + 4 * hh, ct, z);
 }
 
 struct LemBwdArgs {
@@ -181,6 +188,8 @@ struct LemBwdArgs {
     float dt;
     const float* rec_t;  // 16 transposed chunks: g1 x4, lin x4, g2 x4, g3 x4 (consumption order)
     float* dg;           // [N][T][512]: dg1 | dg2 | dg3 | dl (the row order of weights, then weights_lin_z)
+    const float* y0;     // the forward's initial states (NULL = zeros)
+    const float* z0;
 };
 
 __global__ __launch_bounds__(256) void lem_bptt_kernel(LemBwdArgs a) {
@@ -214,6 +223,7 @@ __global__ __launch_bounds__(256) void lem_bptt_kernel(LemBwdArgs a) {
             tile_load(st + SV_A1 * plane, ct, a1);
             tile_load(st + SV_D * plane, ct, d);
             if (t > 0) tile_load(st - H + SV_Y * plane, ct, yp);
+            else if (a.y0) tile_load(a.y0 + (size_t)nc * H + 4 * hh, ct, yp);
             else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) yp[r] = 0.f;
@@ -238,6 +248,7 @@ __global__ __launch_bounds__(256) void lem_bptt_kernel(LemBwdArgs a) {
             tile_load(st + SV_A2 * plane, ct, a2);
             tile_load(st + SV_C * plane, ct, cc);
             if (t > 0) tile_load(st - H + SV_Z * plane, ct, zp);
+            else if (a.z0) tile_load(a.z0 + (size_t)nc * H + 4 * hh, ct, zp);
             else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zp[r] = 0.f;
@@ -296,12 +307,14 @@ extern "C" int64_t msmp_lem_saved_floats(int64_t n_nodes, int t_len) {
 }
 
 extern "C" int msmp_lem_train_fwd_f32(const float* xin, int64_t n_nodes, int t_len, int ninp, float dt, const float* packed,
-                                      float* saved, float* y_out, msmp_stream_t stream) {
-    MSMP_REQUIRE(xin && packed && saved && y_out, MSMP_ERR_ARG, "msmp_lem_train_fwd_f32: null pointer");
+                                      const float* y0, const float* z0, float* saved, float* y_out, float* z_out,
+                                      msmp_stream_t stream) {
+    MSMP_REQUIRE(xin && packed && y_out, MSMP_ERR_ARG, "msmp_lem_train_fwd_f32: null pointer");
+    MSMP_REQUIRE((y0 != nullptr) == (z0 != nullptr), MSMP_ERR_ARG, "msmp_lem_train_fwd_f32: give both initial states or none");
     MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31) && t_len >= 1, MSMP_ERR_ARG, "msmp_lem_train_fwd_f32: bad sizes");
     MSMP_REQUIRE(ninp >= 1 && ninp <= LEM_MAX_INP, MSMP_ERR_UNSUPPORTED, "msmp_lem_train_fwd_f32: ninp=%d not in 1..%d", ninp, LEM_MAX_INP);
     const LemLayout L = lem_layout();
-    LemTrainArgs a{xin, (long)n_nodes, t_len, dt, packed + L.rec, packed + L.bias, packed + L.wx, saved, y_out};
+    LemTrainArgs a{xin, (long)n_nodes, t_len, dt, packed + L.rec, packed + L.bias, packed + L.wx, saved, y_out, y0, z0, z_out};
     const unsigned grid = (unsigned)((n_nodes + 31) / 32);
     hipStream_t st = (hipStream_t)stream;
     switch ((ninp + 1) / 2) {
@@ -313,11 +326,12 @@ extern "C" int msmp_lem_train_fwd_f32(const float* xin, int64_t n_nodes, int t_l
     return check_launch("lem_train_fwd_kernel");
 }
 
-extern "C" int msmp_lem_train_bwd_f32(const float* grad_y, const float* saved, int64_t n_nodes, int t_len, float dt,
-                                      const float* packed_bwd, float* dg_out, msmp_stream_t stream) {
+extern "C" int msmp_lem_train_bwd_f32(const float* grad_y, const float* saved, const float* y0, const float* z0, int64_t n_nodes,
+                                      int t_len, float dt, const float* packed_bwd, float* dg_out, msmp_stream_t stream) {
     MSMP_REQUIRE(grad_y && saved && packed_bwd && dg_out, MSMP_ERR_ARG, "msmp_lem_train_bwd_f32: null pointer");
     MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31) && t_len >= 1 && dt != 0.f, MSMP_ERR_ARG, "msmp_lem_train_bwd_f32: bad sizes");
-    LemBwdArgs a{grad_y, saved, (long)n_nodes, t_len, dt, packed_bwd, dg_out};
+    MSMP_REQUIRE((y0 != nullptr) == (z0 != nullptr), MSMP_ERR_ARG, "msmp_lem_train_bwd_f32: give both initial states or none");
+    LemBwdArgs a{grad_y, saved, (long)n_nodes, t_len, dt, packed_bwd, dg_out, y0, z0};
     const unsigned grid = (unsigned)((n_nodes + 31) / 32);
     hipLaunchKernelGGL(lem_bptt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("lem_bptt_kernel");

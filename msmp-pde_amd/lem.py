@@ -34,12 +34,12 @@ class LEMcuda(nn.Module):
         for w in self.parameters():
             w.data.uniform_(-stdv, +stdv)
 
-    def forward(self, inputs):
-        """inputs [T, N, ninp] -> final y [N, nhid]."""
+    def forward(self, inputs, states=None, return_state=False):
+        """inputs [T, N, ninp] -> final y [N, nhid] (and z with return_state); `states` = (y0, z0) as in the reference
+        (models_gnn.py:325-332), default zeros."""
         t_len, n, _ = inputs.shape
         nh = self.nhid
-        y = inputs.new_zeros(n, nh)
-        z = inputs.new_zeros(n, nh)
+        y, z = (inputs.new_zeros(n, nh), inputs.new_zeros(n, nh)) if states is None else states
         wy, wx = self.weights[:, :nh].t().contiguous(), self.weights[:, nh:].t().contiguous()
         zy, zx = self.weights_lin_z[:, :nh].t().contiguous(), self.weights_lin_z[:, nh:].t().contiguous()
         # input projections for all steps at once (the recurrent part stays sequential)
@@ -51,7 +51,29 @@ class LEMcuda(nn.Module):
             dt_ = self.dt * torch.sigmoid(g[:, nh:2 * nh])
             z = (1.0 - dt_) * z + dt_ * torch.tanh(g[:, 2 * nh:])
             y = (1.0 - dt_bar) * y + dt_bar * torch.tanh(torch.addmm(lx[t], z, zy))
-        return y
+        return (y, z) if return_state else y
+
+
+def _padded_inputs(xin):
+    """xin [N, T, ninp] -> float32, rows zero-padded to msmp_lem_input_stride(ninp), contiguous."""
+    ninp = xin.shape[2]
+    stride = lib().msmp_lem_input_stride(ninp)
+    x = xin.detach().to(torch.float32)
+    return (torch.nn.functional.pad(x, (0, stride - ninp)) if stride != ninp else x).contiguous()
+
+
+def _state(t):
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+def _train_forward(owner, x, ninp, y0, z0, saved):
+    """msmp_lem_train_fwd_f32: the exact-fp32 recurrence from the states (y0, z0) (None = zeros) -> (y_T, z_T)."""
+    n, t_len = x.shape[0], x.shape[1]
+    out = torch.empty(n, owner.nhid, dtype=torch.float32, device=x.device)
+    z_out = torch.empty_like(out)
+    check(lib().msmp_lem_train_fwd_f32(ptr(x), n, t_len, ninp, owner.rnn.dt, ptr(owner._pack(None)), ptr(y0), ptr(z0), ptr(saved),
+                                       ptr(out), ptr(z_out), current_stream()), 'msmp_lem_train_fwd_f32')
+    return out, z_out
 
 
 class _LEMTrainFunction(torch.autograd.Function):
@@ -60,24 +82,22 @@ class _LEMTrainFunction(torch.autograd.Function):
     by the weight-gradient GEMMs over the N*T rows.  Like the reference it returns no gradient for the step inputs."""
 
     @staticmethod
-    def forward(ctx, owner, xin, weights, weights_lin_z, bias, bias_lin_z):
-        L = lib()
+    def forward(ctx, owner, xin, weights, weights_lin_z, bias, bias_lin_z, y0=None, z0=None):
+        x = _padded_inputs(xin)
         n, t_len, ninp = xin.shape
-        stride = L.msmp_lem_input_stride(ninp)
-        x = xin.detach().to(torch.float32)
-        x = (torch.nn.functional.pad(x, (0, stride - ninp)) if stride != ninp else x).contiguous()
-        saved = torch.empty(L.msmp_lem_saved_floats(n, t_len), dtype=torch.float32, device=x.device)
-        out = torch.empty(n, owner.nhid, dtype=torch.float32, device=x.device)
-        check(L.msmp_lem_train_fwd_f32(ptr(x), n, t_len, ninp, owner.rnn.dt, ptr(owner._pack(None)), ptr(saved), ptr(out),
-                                       current_stream()), 'msmp_lem_train_fwd_f32')
-        ctx.save_for_backward(x, saved, weights, weights_lin_z)
+        saved = torch.empty(lib().msmp_lem_saved_floats(n, t_len), dtype=torch.float32, device=x.device)
+        y0, z0 = _state(y0), _state(z0)
+        out, z_out = _train_forward(owner, x, ninp, y0, z0, saved)
+        ctx.save_for_backward(x, saved, weights, weights_lin_z, *([y0, z0] if y0 is not None else []))
         ctx.dt, ctx.ninp = owner.rnn.dt, ninp
-        return out
+        ctx.mark_non_differentiable(z_out)          # the carried state: a constant for the next call (models_gnn.py:350-353)
+        return out, z_out
 
     @staticmethod
-    def backward(ctx, grad_y):
+    def backward(ctx, grad_y, _grad_z=None):
         L = lib()
-        x, saved, weights, weights_lin_z = ctx.saved_tensors
+        x, saved, weights, weights_lin_z, *states = ctx.saved_tensors
+        y0, z0 = states if states else (None, None)
         n, t_len, stride = x.shape
         nh = weights_lin_z.shape[0]
         blob = torch.empty(L.msmp_packed_lem_bwd_floats(), dtype=torch.float32, device=x.device)
@@ -85,17 +105,20 @@ class _LEMTrainFunction(torch.autograd.Function):
         check(L.msmp_pack_lem_bwd_f32(ptr(w), ptr(wz), ctx.ninp, ptr(blob), current_stream()), 'msmp_pack_lem_bwd_f32')
         dg = torch.empty(n * t_len, 4 * nh, dtype=torch.float32, device=x.device)
         g = grad_y.to(torch.float32).contiguous()
-        check(L.msmp_lem_train_bwd_f32(ptr(g), ptr(saved), n, t_len, ctx.dt, ptr(blob), ptr(dg), current_stream()),
+        check(L.msmp_lem_train_bwd_f32(ptr(g), ptr(saved), ptr(y0), ptr(z0), n, t_len, ctx.dt, ptr(blob), ptr(dg), current_stream()),
               'msmp_lem_train_bwd_f32')
         planes = saved.view(6, n, t_len, nh)
         xs = x.view(n * t_len, stride)[:, :ctx.ninp]
-        y_prev = torch.nn.functional.pad(planes[4][:, :-1], (0, 0, 1, 0)).reshape(n * t_len, nh)     # y_{t-1}, y_{-1} = 0
+        if y0 is None:
+            y_prev = torch.nn.functional.pad(planes[4][:, :-1], (0, 0, 1, 0)).reshape(n * t_len, nh)     # y_{t-1}, y_{-1} = 0
+        else:
+            y_prev = torch.cat((y0[:, None, :], planes[4][:, :-1]), 1).reshape(n * t_len, nh)            # y_{-1} = y0
         yx = torch.cat((y_prev, xs), 1)
         zx = torch.cat((planes[5].reshape(n * t_len, nh), xs), 1)
         from .autograd import grad_weights          # weight / bias gradients: sums over the N*T rows (msmp_grad_weights_f32)
         g = grad_weights([(dg[:, :nh], yx), (dg[:, nh:2 * nh], yx), (dg[:, 2 * nh:3 * nh], yx), (dg[:, 3 * nh:], zx)])
         d_w, d_b = torch.cat(g[0:6:2], 0), torch.cat(g[1:6:2], 0)
-        return None, None, d_w.to(weights.dtype), g[6].to(weights_lin_z.dtype), d_b, g[7]
+        return None, None, d_w.to(weights.dtype), g[6].to(weights_lin_z.dtype), d_b, g[7], None, None
 
 
 class LEM(nn.Module):
@@ -125,7 +148,7 @@ class LEM(nn.Module):
         if not (xin.is_cuda and self.TRAIN_KERNELS and self.nhid == 128):
             return self.rnn(xin.permute(1, 0, 2).contiguous())
         r = self.rnn
-        return _LEMTrainFunction.apply(self, xin, r.weights, r.weights_lin_z, r.bias, r.bias_lin_z)
+        return _LEMTrainFunction.apply(self, xin, r.weights, r.weights_lin_z, r.bias, r.bias_lin_z)[0]
 
     def _pack(self, mlp):
         ps = [self.rnn.weights, self.rnn.weights_lin_z, self.rnn.bias, self.rnn.bias_lin_z]
@@ -171,3 +194,40 @@ class LEM(nn.Module):
         check(L.msmp_lem_encoder_f32(ptr(xin), n, t_len, self.ninp, self.rnn.dt, ptr(self._pack(mlp)),
                                      int(mlp is not None), ptr(out), current_stream()), 'msmp_lem_encoder_f32')
         return out
+
+
+class LEMS(LEM):
+    """experiments/models_gnn.py:345-362: the LEM that keeps (all_y[-1], all_z[-1]) of a call as the initial states of the next
+    (`reset_states()` starts a new unrolling sequence; train_helper.py:144-145, 199-200).  The carried states are constants for
+    the next call.  Runs on the exact-fp32 recurrence kernel (msmp_lem_train_fwd_f32; with autograd its BPTT pair), which takes
+    initial states; the weight-stationary inference kernel starts from zeros and is not used here."""
+
+    def __init__(self, ninp, nhid, dt=1.):
+        super().__init__(ninp, nhid, dt)
+        self.states = None
+
+    def reset_states(self):
+        self.states = None
+
+    def forward(self, inputs):
+        return self.forward_nodes(inputs.permute(1, 0, 2))
+
+    def forward_nodes(self, xin):
+        y0, z0 = self.states if self.states is not None else (None, None)
+        r = self.rnn
+        if not (xin.is_cuda and self.nhid == 128):
+            raise RuntimeError('LEMS needs CUDA tensors (HIP path only, no CPU fallback)')
+        if torch.is_grad_enabled() and any(p.requires_grad for p in r.parameters()):
+            if self.TRAIN_KERNELS:
+                y, z = _LEMTrainFunction.apply(self, xin, r.weights, r.weights_lin_z, r.bias, r.bias_lin_z, y0, z0)
+            else:
+                y, z = r(xin.permute(1, 0, 2).contiguous(), None if y0 is None else (y0, z0), return_state=True)
+        else:
+            y, z = _train_forward(self, _padded_inputs(xin), xin.shape[2], _state(y0), _state(z0), None)
+        self.states = (y.detach(), z.detach())
+        return y
+
+    def encode(self, *args, **kwargs):
+        raise RuntimeError('LEMS is stateful: use forward / forward_nodes')
+
+    encode_nodes = encode

@@ -23,7 +23,7 @@ from torch import nn
 from ._lib import lib, check, ptr, current_stream, PARAM_EPOCH
 from .graph import structure_of
 from .layers import GNN_Layer, GNN_LayerLin, Swish, mp_layer
-from .lem import LEM
+from .lem import LEM, LEMS
 
 _DECODER = {20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}   # models_gnn.py:210-224; models_gnn2D.py:79-88
 
@@ -82,6 +82,7 @@ class _SolverBase(nn.Module):
     TWO_D = False
     GATED = False
     LEM_ENCODER = False
+    ALWAYS_SAVE = False     # MP_PDE_SolverLEMLinGatedSave: LEMS regardless of the constructor argument
     LSTM_ENCODER = False    # the LSTM ablations: torch.nn.LSTM (MIOpen) in place of the LEM, everything after it unchanged
     G2 = False
     RETURN_DIFF = False     # MSSMP_PDE_Solver_sub: forward returns the decoder output, not the Euler update
@@ -91,8 +92,7 @@ class _SolverBase(nn.Module):
         super().__init__()
         allowed = (25, 50) if self.TWO_D else (20, 25, 50)
         assert time_window in allowed
-        if save_state:
-            raise NotImplementedError('the state-saving LEMS variant is out of scope (SURVEY.md section 2)')
+        self.save_state = save_state if self.LEM_ENCODER else None        # models_gnn2D.py:325, 360-363: LEM or the stateful LEMS
         self.pde = pde
         self.out_features = time_window
         self.hidden_features = hidden_features
@@ -112,7 +112,7 @@ class _SolverBase(nn.Module):
             self.lstmoutput_mlp = nn.Sequential(_lin(hidden_features, hidden_features), Swish(),
                                                 _lin(hidden_features, hidden_features), Swish())
         elif self.LEM_ENCODER:
-            self.embedding_lem = LEM(2 + len(eq_variables) + comps, hidden_features)
+            self.embedding_lem = (LEMS if (save_state or self.ALWAYS_SAVE) else LEM)(2 + len(eq_variables) + comps, hidden_features)
             self.lemoutput_mlp = nn.Sequential(_lin(hidden_features, hidden_features), Swish(),
                                                _lin(hidden_features, hidden_features), Swish())
         else:
@@ -156,8 +156,8 @@ class _SolverBase(nn.Module):
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.embedding_mlp.parameters()):
                 return self.embedding_mlp(torch.cat((u, pos_x, variables), -1))      # differentiable PyTorch path
             return self._embed_hip(u, pos_x, variables)
-        tw = self.time_window
-        n = u.shape[0]
+        if isinstance(self.embedding_lem, LEMS):       # stateful encoder: always the state-taking recurrence kernel
+            return self.lemoutput_mlp(self.embedding_lem.forward_nodes(self._step_inputs(u, pos_x, pos_t, variables, dt)))
         grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.embedding_lem.parameters())
         if not grad:                    # step inputs assembled inside the kernel (no [N, T, ninp] tensor)
             h = self.embedding_lem.encode_nodes(u, pos_x, pos_t, variables, dt, self.TWO_D, self.lemoutput_mlp)
@@ -326,6 +326,12 @@ class MP_PDE_Solver2DLEMLinG2(_SolverBase):
     TWO_D, LEM_ENCODER, G2, LAYER = True, True, True, GNN_LayerLin
 
 
+class MP_PDE_SolverLEMLinGatedSave(_SolverBase):
+    """experiments/models_gnn.py:1747-1905 (train.py name 'SaveMSMP-PDE'): MSMP-PDE whose LEM keeps its hidden states from one
+    call of a rollout to the next (`model.embedding_lem.reset_states()` between sequences)."""
+    GATED, LEM_ENCODER, ALWAYS_SAVE, LAYER = True, True, True, GNN_LayerLin
+
+
 class MP_PDE_SolverLSTMLin(_SolverBase):
     """experiments/models_gnn.py:770-907 (train.py name 'LSTM')."""
     LSTM_ENCODER = True
@@ -377,7 +383,7 @@ MODEL_NAMES = {   # experiments/train.py:34-183 getModel names -> class
     'MP-PDE': MP_PDE_Solver, 'Gated': MP_PDE_SolverGated, 'MSMP-PDE': MP_PDE_SolverLEMLinGated,
     'MP-PDE2D': MP_PDE_Solver2D, 'Gated2D': MP_PDE_Solver2DGated, 'MSMP-PDE2D': MP_PDE_Solver2DLEMLinGated,
     'LEM': MP_PDE_SolverLEMLin, 'LEM2D': MP_PDE_Solver2DLEMLin, 'MSG2-PDE2D': MP_PDE_Solver2DLEMLinG2,
-    'MSSMP-PDE': MSSMP_PDE_Solver,
+    'MSSMP-PDE': MSSMP_PDE_Solver, 'SaveMSMP-PDE': MP_PDE_SolverLEMLinGatedSave,
     'LSTM': MP_PDE_SolverLSTMLin, 'LSTMGated': MP_PDE_SolverLSTMLinGated, 'LSTM2D': MP_PDE_Solver2DLSTMLin,
     'LSTMGated2D': MP_PDE_Solver2DLSTMLinGated,
 }

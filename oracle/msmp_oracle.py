@@ -125,16 +125,18 @@ def conv1d(x, w, b, stride):
     return np.einsum('nclk,ock->nol', win, w, optimize=True) + b[None, :, None]
 
 
-def lem_forward(inputs, weights, weights_lin_z, bias, bias_lin_z, dt=1.0):
+def lem_forward(inputs, weights, weights_lin_z, bias, bias_lin_z, dt=1.0, states=None, return_state=False):
     """LEM recurrence behind `lem_cuda.forward` (call site experiments/models_gnn.py:285-342; the
     extension's source is absent, so this follows the published LEM cell):
       X = [y, x_t]; g = X W^T + b split in 3; dt_bar = dt s(g1); dt_ = dt s(g2);
       z <- (1-dt_) z + dt_ tanh(g3); X2 = [z, x_t]; y <- (1-dt_bar) y + dt_bar tanh(X2 Wz^T + bz).
-    inputs [T, N, ninp]; returns all_y[-1] (LEM.forward, :340-342).  PARITY UNPINNED."""
+    inputs [T, N, ninp]; returns all_y[-1] (LEM.forward, :340-342).  `states` = (y0, z0) as LEMcuda.forward takes them
+    (:325-332; the stateful LEMS carries (all_y[-1], all_z[-1]) from call to call, :345-357); return_state adds all_z[-1].
+    PARITY UNPINNED."""
     t_len, n, _ = inputs.shape
     nh = weights_lin_z.shape[0]
-    y = np.zeros((n, nh), dtype=inputs.dtype)
-    z = np.zeros((n, nh), dtype=inputs.dtype)
+    y = np.zeros((n, nh), dtype=inputs.dtype) if states is None else np.asarray(states[0], dtype=inputs.dtype)
+    z = np.zeros((n, nh), dtype=inputs.dtype) if states is None else np.asarray(states[1], dtype=inputs.dtype)
     for t in range(t_len):
         g = np.concatenate((y, inputs[t]), axis=1) @ weights.T + bias
         dt_bar = dt * sigmoid(g[:, :nh])
@@ -142,7 +144,7 @@ def lem_forward(inputs, weights, weights_lin_z, bias, bias_lin_z, dt=1.0):
         z = (1.0 - dt_) * z + dt_ * np.tanh(g[:, 2 * nh:])
         lin = np.concatenate((z, inputs[t]), axis=1) @ weights_lin_z.T + bias_lin_z
         y = (1.0 - dt_bar) * y + dt_bar * np.tanh(lin)
-    return y
+    return (y, z) if return_state else y
 
 
 def lstm_forward(inputs, w_ih, w_hh, b_ih, b_hh):
@@ -163,6 +165,7 @@ def lstm_forward(inputs, w_ih, w_hh, b_ih, b_hh):
 # solver forward passes
 # --------------------------------------------------------------------------------------------
 KINDS_1D = ('MP_PDE_Solver', 'MP_PDE_SolverGated', 'MP_PDE_SolverLEMLinGated', 'MP_PDE_SolverLEMLin', 'MSSMP_PDE_Solver',
+            'MP_PDE_SolverLEMLinGatedSave',
             'MP_PDE_SolverLSTMLin', 'MP_PDE_SolverLSTMLinGated')
 KINDS_2D = ('MP_PDE_Solver2D', 'MP_PDE_Solver2DGated', 'MP_PDE_Solver2DLEMLinGated', 'MP_PDE_Solver2DLEMLin',
             'MP_PDE_Solver2DLEMLinG2', 'MP_PDE_Solver2DLSTMLin', 'MP_PDE_Solver2DLSTMLinGated')
@@ -197,7 +200,7 @@ def build_variables(kind, data, pde, eq_variables):
 
 
 def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=6, dtype=np.float64,
-                   parts=False, decoder_diff=False):
+                   parts=False, decoder_diff=False, lem_states=None):
     """forward(data) of the in-scope solver classes.
     MP_PDE_Solver               experiments/models_gnn.py:229-281
     MP_PDE_SolverGated          experiments/models_gnn.py:1162-1218
@@ -208,6 +211,8 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
     MP_PDE_SolverLEMLin         experiments/models_gnn.py:696-756    (LEM encoder + plain GNN_Layer stack; train.py 'LEM')
     MP_PDE_Solver2DLEMLin       experiments/models_gnn2D.py:1003-1057 (same, 2-D; train.py 'LEM2D')
     MP_PDE_Solver2DLEMLinG2     experiments/models_gnn2D.py:565-620   (gradient-gated blend; train.py 'MSG2-PDE2D')
+    MP_PDE_SolverLEMLinGatedSave  experiments/models_gnn.py:1747-1905 (and save_state=True of the 2-D class): pass a dict as
+                                `lem_states`; it carries the LEM states from call to call ({} or reset = a new sequence)
     MSSMP_PDE_Solver            experiments/models_gnn.py:1721-1745   (two MSMP-PDE networks `diff.*`, `scale.*`, each returning
                                 its decoder output (:1679-1682, decoder_diff=True); train.py 'MSSMP-PDE')
     `sd` maps the reference's state_dict key names to arrays.  Row S1."""
@@ -244,7 +249,11 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
             mlp = 'lstmoutput_mlp'
         else:
             h = lem_forward(lem_in, sd['embedding_lem.rnn.weights'], sd['embedding_lem.rnn.weights_lin_z'],
-                            sd['embedding_lem.rnn.bias'], sd['embedding_lem.rnn.bias_lin_z'], 1.0)
+                            sd['embedding_lem.rnn.bias'], sd['embedding_lem.rnn.bias_lin_z'], 1.0,
+                            states=None if lem_states is None else lem_states.get('states'), return_state=lem_states is not None)
+            if lem_states is not None:      # the Save variants: (all_y[-1], all_z[-1]) go into the next call (models_gnn.py:350-353)
+                lem_states['states'] = h
+                h = h[0]
             mlp = 'lemoutput_mlp'
         h = swish(linear(h, sd[mlp + '.0.weight'], sd[mlp + '.0.bias']))
         h = swish(linear(h, sd[mlp + '.2.weight'], sd[mlp + '.2.bias']))

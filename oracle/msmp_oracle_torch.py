@@ -43,12 +43,11 @@ def mp_layer(sd, prefix, x, u, pos, variables, ei, batch, b, lin):
     return instance_norm(pre, batch, b)
 
 
-def lem_forward(inputs, w, wz, bias, bz, dt=1.0):
+def lem_forward(inputs, w, wz, bias, bz, dt=1.0, states=None):
     """See msmp_oracle.lem_forward (PARITY UNPINNED)."""
     t_len, n, _ = inputs.shape
     nh = wz.shape[0]
-    y = torch.zeros(n, nh, dtype=inputs.dtype)
-    z = torch.zeros(n, nh, dtype=inputs.dtype)
+    y, z = (torch.zeros(n, nh, dtype=inputs.dtype), torch.zeros(n, nh, dtype=inputs.dtype)) if states is None else states
     for t in range(t_len):
         g = F.linear(torch.cat((y, inputs[t]), 1), w, bias)
         dt_bar = dt * torch.sigmoid(g[:, :nh])
@@ -58,7 +57,8 @@ def lem_forward(inputs, w, wz, bias, bz, dt=1.0):
     return y
 
 
-def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=6, as_numpy=True, decoder_diff=False):
+def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=6, as_numpy=True, decoder_diff=False,
+                   lem_initial_states=None):
     """forward(data) of the six in-scope solver classes (see msmp_oracle.solver_forward for the line map).
     `sd` values may be float64 torch tensors that require grad (as_numpy=False keeps the autograd graph:
     used to check the product's gradients)."""
@@ -98,7 +98,8 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
             mlp = 'lstmoutput_mlp'
         else:
             h = lem_forward(torch.stack(steps, 0), sd['embedding_lem.rnn.weights'], sd['embedding_lem.rnn.weights_lin_z'],
-                            sd['embedding_lem.rnn.bias'], sd['embedding_lem.rnn.bias_lin_z'], 1.0)
+                            sd['embedding_lem.rnn.bias'], sd['embedding_lem.rnn.bias_lin_z'], 1.0,
+                            states=None if lem_initial_states is None else tuple(t64(a) for a in lem_initial_states))
             mlp = 'lemoutput_mlp'
         h = swish(F.linear(h, sd[mlp + '.0.weight'], sd[mlp + '.0.bias']))
         h = swish(F.linear(h, sd[mlp + '.2.weight'], sd[mlp + '.2.bias']))

@@ -286,3 +286,51 @@ def test_other_grid_resolutions_vs_oracle(mp, nx):
     for name, p in model.named_parameters():
         e = (p.grad.double().cpu() - sd64[name].grad).abs().max().item()
         assert e < 2e-3 * sd64[name].grad.abs().max().item() + 1e-4 * scale, (name, e)
+
+
+@pytest.mark.parametrize('kind,exp,kw', [('MP_PDE_SolverLEMLinGatedSave', 'E2', {}), ('MP_PDE_Solver2DLEMLinGated', 'RPU', {'save_state': True})])
+def test_state_saving_lem_rollout_vs_oracle(mp, kind, exp, kw):
+    """The `Save` variants (models_gnn.py:345-362, 1747-1905; models_gnn2D.py:360-363): the LEM's final states of one call are
+    the initial states of the next.  A 3-step rollout through create_next_graph against the oracle carrying the states
+    explicitly (a 25-step LEM largely forgets its initial state, so the sensitive check of the carry is the kernel-level
+    test_lems_state_carry in test_gpu_training.py); after reset_states() the stateless result is reproduced; and the parameter gradients of a call that starts from
+    carried states against float64 autograd through the oracle."""
+    from oracle import msmp_oracle_torch as OT
+    torch.manual_seed(13)
+    case = synthetic_case(mp, exp, bsz=4, seed=12)
+    model = getattr(mp, kind)(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=2, **kw).cuda().eval()
+    assert isinstance(model.embedding_lem, mp.LEMS) and hasattr(model.embedding_lem, 'reset_states')
+    okind = 'MP_PDE_SolverLEMLinGatedSave' if exp == 'E2' else 'MP_PDE_Solver2DLEMLinGated'
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    g, graph = case.graph_np(), case.graph.to('cuda')
+    carry, outs = {}, []
+    with torch.no_grad():
+        for r in range(3):
+            ref = O.solver_forward(okind, sd, g, case.pde, TW, case.eqv, 2, lem_states=carry)
+            out = model(graph)
+            outs.append(out)
+            err = np.abs(out.double().cpu().numpy() - ref).max()
+            print(f'{kind}: stateful rollout step {r}: {err:.3e}')
+            assert err < TOL, (r, err)
+            if r < 2:
+                steps = [50 + TW * (r + 1)] * 4
+                _, labels = case.creator.create_data(case.u_super, steps)
+                graph = case.creator.create_next_graph(graph, out, labels, steps)
+                g = O.create_next_graph(repr(case.pde), case.pde, TW, g, ref, labels.cpu().numpy(), steps)
+        stateless = O.solver_forward(okind, sd, g, case.pde, TW, case.eqv, 2)
+        model.embedding_lem.reset_states()
+        assert np.abs(model(graph).double().cpu().numpy() - stateless).max() < TOL
+    # gradients of a call that starts from carried states (which are constants)
+    y0, z0 = (t.clone() for t in model.embedding_lem.states)
+    model.train()
+    loss = torch.sqrt(((model(graph) - graph.y.to(torch.float32)) ** 2).sum())
+    loss.backward()
+    sd64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    out64 = OT.solver_forward(okind, sd64, g, case.pde, TW, case.eqv, 2, as_numpy=False, lem_initial_states=(y0.cpu(), z0.cpu()))
+    ref_loss = torch.sqrt(((out64 - torch.tensor(g.y).double()) ** 2).sum())
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * ref_loss.item()
+    scale = max(v.grad.abs().max().item() for v in sd64.values())
+    for name, p in model.named_parameters():
+        e = (p.grad.double().cpu() - sd64[name].grad).abs().max().item()
+        assert e < 2e-3 * sd64[name].grad.abs().max().item() + 1e-4 * scale, (name, e)

@@ -356,3 +356,39 @@ def test_packed_weights_follow_fused_optimizer_and_data_edits(mp, name):
     want_train, _ = fresh_outputs()
     with torch.no_grad():
         assert torch.equal(model.train()(graph), want_train)
+
+
+@pytest.mark.parametrize('ninp,n,t_len', [(4, 77, 2), (6, 200, 4)])
+def test_lems_state_carry(mp, ninp, n, t_len):
+    """LEMS (models_gnn.py:345-362) on the state-taking recurrence kernel: three consecutive calls with short sequences (so the
+    carried (y, z) dominate the result) against the float64 restatement carrying the states explicitly, under no_grad (saved =
+    NULL path) and with autograd (third call: parameter gradients with the carried states as constants); reset_states()."""
+    import copy
+    from msmp_pde_amd.lem import LEMS
+    torch.manual_seed(3 + ninp)
+    lem = LEMS(ninp, 128).cuda()
+    ref = copy.deepcopy(lem).double()
+    xs = [torch.randn(n, t_len, ninp, device='cuda') for _ in range(3)]
+    states = None
+    with torch.no_grad():
+        for k in range(2):
+            y = lem.forward_nodes(xs[k])
+            y64, z64 = ref.rnn(xs[k].double().permute(1, 0, 2).contiguous(), states, return_state=True)
+            states = (y64, z64)
+            assert (y.double() - y64).abs().max().item() < 1e-5
+            assert (lem.states[1].double() - z64).abs().max().item() < 1e-5
+    y = lem.forward_nodes(xs[2])                                   # with autograd, from carried states
+    w_out = torch.randn(n, 128, device='cuda')
+    (y * w_out).sum().backward()
+    y64 = ref.rnn(xs[2].double().permute(1, 0, 2).contiguous(), tuple(s.detach() for s in states))
+    (y64 * w_out.double()).sum().backward()
+    assert (y.double() - y64).abs().max().item() < 1e-5
+    for (k, p), q in zip(lem.named_parameters(), ref.parameters()):
+        assert (p.grad.double() - q.grad).abs().max().item() < 1e-4 * q.grad.abs().max().item(), k
+    # the states really matter at this sequence length, and reset_states() drops them
+    with torch.no_grad():
+        lem.reset_states()
+        y_reset = lem.forward_nodes(xs[2])
+        y_zero = ref.rnn(xs[2].double().permute(1, 0, 2).contiguous())
+    assert (y_reset.double() - y_zero).abs().max().item() < 1e-5
+    assert (y_reset - y.detach()).abs().max().item() > 1e-2
