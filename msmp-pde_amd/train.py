@@ -57,4 +57,7 @@ def training_step(model, creator, u_super, x, variables, random_steps, unrolled_
             graph = creator.create_next_graph(graph, pred, labels, steps)
     loss = dp_loss_backward(model, graph)
     optimizer.step()
+    lem = getattr(model, 'embedding_lem', None)            # the Save variants start every sample from fresh LEM states (:144-145)
+    if hasattr(lem, 'reset_states'):
+        lem.reset_states()
     return loss
