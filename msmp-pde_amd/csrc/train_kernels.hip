@@ -186,7 +186,7 @@ extern "C" int msmp_gate_blend_bwd_f32(const float* grad_out, const float* h, co
 // Weight gradients:  dW[m][n] = sum_r A[r][m] B[r][n]  and  db[m] = sum_r A[r][m]  for up to 8 (A, B) pairs in one call
 // (A [R,128] (row stride lda) = gradient of a pre-activation, B [R, >= k2] = the input of that linear layer, R = E or N rows).
 // These GEMMs are 128 x k2 outputs with a reduction over R >> 1000 rows: the library runs them on 36 workgroups
-// (63 us each at R = 9 408); here the rows are split over workgroups (<= 128 splits per pair; exact-fp32 MFMA partial products, the bias column
+// (63 us each at R = 9 408); here the rows are split over workgroups (<= 512 splits per pair; exact-fp32 MFMA partial products, the bias column
 // as a virtual all-ones column k2 of B), and a second kernel sums the partials in a fixed order (deterministic).
 // ----------------------------------------------------------------------------------------------
 namespace msmp {
@@ -276,11 +276,12 @@ __global__ __launch_bounds__(256) void grad_weight_reduce_kernel(GradWeightArgs 
 }
 
 static int gw_tiles(int k2) { const int t = (k2 + 1 + 31) / 32; return t <= 5 ? 5 : t <= 9 ? 9 : t <= 10 ? 10 : -1; }
-// rows per workgroup: 128 (8 pairs of a training batch of 16 graphs already make ~350 workgroups), more once a pair would
-// exceed 128 splits -- the partial products (splits x 128 x 32 nt floats) are written and re-read by the reduction
+// rows per workgroup: 128, more once a pair would exceed 512 splits (the partial products, splits x 128 x 32 nt floats, are
+// written and re-read by the reduction).  Measured per training iteration with limits 128 / 256 / 512 (E2 MSMP-PDE): batch 16
+// 7.1 / 7.0 / 6.3 ms (the LEM pairs have 40 000 rows), batch 128 15.0 / 14.9 / 14.9, batch 512 51.1 / 49.7 / 48.9.
 static int gw_rows_per_split(int64_t rows) {
     int64_t rps = 128;
-    while ((rows + rps - 1) / rps > 128) rps *= 2;
+    while ((rows + rps - 1) / rps > 512) rps *= 2;
     return (int)rps;
 }
 
