@@ -1,28 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- rollout-steps/sec of the MSMP-PDE message-passing rollout step on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--graphs 2048] [--model MSMP-PDE]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--graphs 2048] [--model MSMP-PDE] [--scaling strong|weak]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1]): E2 (Burgers-type CE, nx=100, time_window=25, radius graph n=3,
-588 edges/graph), model MSMP-PDE = MP_PDE_SolverLEMLinGated (6 gated layer pairs), 2048 graphs per GPU,
+588 edges/graph), model MSMP-PDE = MP_PDE_SolverLEMLinGated (6 gated layer pairs), a 2048-graph batch,
 random-init weights, synthetic trajectories resident in HBM.  One "step" = one rollout step of the
 reference's unrolled evaluation (experiments/train_helper.py:255-261): create_next_graph (state update)
-+ model(graph) under no_grad, on the rank's whole batch.  Multi-GPU: graphs are independent, so every
-rank runs its own 2048-graph batch with no data-path collective (weak scaling); value = total rollout
-steps of all ranks / max-over-ranks time.
++ model(graph) under no_grad, on the whole batch.
+
+Multi-GPU: graphs are independent, so the batch is sharded by graph with no
+data-path collective.  `--gpus N` without a torchrun environment starts N child processes itself (one per GPU, before
+this process touches the GPU; a process that has initialised the GPU is never exec'd).  The headline at N > 1 is the
+metric's own form, STRONG scaling: the 2048-graph batch split over the ranks (msmp_pde_amd.dist.shard_range), value =
+steps / max-over-ranks time; the same run also measures WEAK scaling (2048 graphs on every rank, object `weak`).
+`--scaling weak` makes the weak number the headline instead.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (edge-message MLP): algorithmic FLOPs of the dense formulation
-                (2*E*K_msg*H + 2*E*H*H per launch) / mean launch time measured with
-                HIP events on the launch stream inside the timed region, vs the fp32 MFMA peak.
-  scatter_hbm   row L2 standalone: achieved HBM GB/s of the CSR segmented-mean kernel on a message tensor of the workload's size
-                (outside the timed region; the default layer path fuses the mean into the message kernel).
+  roofline      dominant kernel (the edge-message kernel): see DESIGN.md section 6.
+  scatter_hbm   row L2 standalone: achieved HBM GB/s of the CSR segmented-mean kernel at the workload's size.
   cpu_baseline  the CPU oracle (torch-CPU float64 edition, kind "port") timed on this host on a bounded sample.
+  config0       BASELINE.json configs[0] (E2 MP-PDE, 32 graphs): the HIP path and the CPU port side by side.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,49 +38,86 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_FP16_MFMA_TFLOPS = 2500.0    # same guide, "Peak BF16/FP16 MFMA" (dense)
+PEAK_HBM_GBPS = 8000.0            # same guide, HBM3E peak (spec); ~6300 achievable
 H = 128
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--graphs', type=int, default=2048, help='graphs per GPU')
-    ap.add_argument('--model', default='MSMP-PDE', help='MSMP-PDE | Gated | MP-PDE')
+    ap.add_argument('--graphs', type=int, default=2048, help='graphs of the batch (strong: in total; weak: per GPU)')
+    ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong', help='headline mode at N > 1 (SURVEY 8d: the metric is the 2048-graph batch split over the GPUs)')
+    ap.add_argument('--model', default='MSMP-PDE', help='MSMP-PDE | Gated | MP-PDE | ...')
     ap.add_argument('--experiment', default='E2')
     ap.add_argument('--neighbors', type=int, default=3, help='n of the graph builder (radius n*dx / knn k); 8, 16 = the MSWG3 edge-count stress of SURVEY 8(d)')
+    ap.add_argument('--preheat-s', type=float, default=1.0, help='untimed steps run for this long before the timed window (sustained clocks, not boost)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip scatter_hbm / config0 / the second scaling mode (profiling runs)')
     ap.add_argument('--cpu-sample-graphs', type=int, default=128)
     ap.add_argument('--cpu-sample-steps', type=int, default=3)
-    ap.add_argument('--dist-backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo lets two ranks share one GPU for testing')
+    ap.add_argument('--dist-backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo lets ranks share one GPU for testing')
     ap.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='msmp_tune override for kernel A/B runs (e.g. lem=1)')
     ap.add_argument('--fp32-mfma', action='store_true', help='use the fp32-MFMA kernels instead of the fp16-split matrix path')
     ap.add_argument('--time-all-kernels', action='store_true', help='event-time every kernel family, not only the dominant one')
-    return ap.parse_args()
+    ap.add_argument('--launcher-selftest', action='store_true', help='(tests) ranks only join the process group and count themselves; needs no GPU')
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(args, kind, eqv):
-    """The oracle (torch-CPU float64 edition, `kind: port`: the reference itself is PyTorch on the CPU)
-    on a bounded sample of the same workload: `cpu_sample_graphs` graphs x `cpu_sample_steps` rollout
-    steps, scaled to the 2048-graph step."""
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without torchrun: this process only spawns (it never touches the GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+def launch_children(args, argv):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def source_hash():
+    """Hash of the kernel sources: stamps profiles/traffic.json so a stale PMC figure is never reported for other code."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, 'msmp-pde_amd', 'csrc')
+    for f in sorted(os.listdir(base)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            h.update(open(os.path.join(base, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(model_name, experiment, graphs_total, sample_graphs, sample_steps, neighbors=3):
+    """The oracle (torch-CPU float64 edition, `kind: port`: the reference itself is PyTorch on the CPU) on a bounded
+    sample of the workload: `sample_graphs` graphs x `sample_steps` rollout steps, scaled to `graphs_total`."""
     import numpy as np
     import torch
     from threadpoolctl import threadpool_limits
     import msmp_pde_amd as mp
-    from msmp_pde_amd.synthetic import make_case
+    from msmp_pde_amd.synthetic import make_case, EXPERIMENTS
     from oracle import msmp_oracle as O, msmp_oracle_torch as OT
+    from types import SimpleNamespace
+    eqv = dict(EXPERIMENTS[experiment])
+    kind = mp.MODEL_NAMES[model_name].__name__
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
     cores = min(avail, 16)          # the GPU box's CPU share for one GPU; BLAS threads actually used
-    b = args.cpu_sample_graphs
+    b = sample_graphs
     torch.manual_seed(0)
-    case = make_case(args.experiment, b, seed=0, device='cuda', dtype=torch.float64, neighbors=args.neighbors)
-    model = mp.MODEL_NAMES[args.model](case.pde, time_window=25, eq_variables=eqv, hidden_layer=6)
+    case = make_case(experiment, b, seed=0, device='cuda', dtype=torch.float64, neighbors=neighbors)
+    model = mp.MODEL_NAMES[model_name](case.pde, time_window=25, eq_variables=eqv, hidden_layer=6)
     sd = {k: v.detach().numpy().astype(np.float64) for k, v in model.state_dict().items()}
     steps = [50] * b
     data, labels = case.creator.create_data(case.u_super, steps)
     g = case.creator.create_graph(data, labels, case.x, case.variables, steps)
-    from types import SimpleNamespace
     gn = SimpleNamespace(**{k: v.detach().cpu().numpy() for k, v in g.__dict__.items() if torch.is_tensor(v)})
     traj = case.u_super.cpu().numpy()
     pde_name = repr(case.pde)
@@ -83,30 +126,96 @@ def cpu_baseline(args, kind, eqv):
     with threadpool_limits(limits=cores):
         pred = OT.solver_forward(kind, sd, gn, case.pde, 25, eqv, 6)
         step = 50
-        for _ in range(args.cpu_sample_steps):
+        for _ in range(sample_steps):
             t0 = time.perf_counter()
             step += 25
             _, lab = O.create_data(traj, [step] * b, 25)
             gn = O.create_next_graph(pde_name, case.pde, 25, gn, pred, lab, [step] * b)
             pred = OT.solver_forward(kind, sd, gn, case.pde, 25, eqv, 6)
             times.append(time.perf_counter() - t0)
-    t_step = float(np.median(times)) * (args.graphs / b)      # scaled to the full batch
+    t_step = float(np.median(times)) * (graphs_total / b)      # scaled to the full batch
+    scaled = f', median step time scaled x{graphs_total / b:g} to {graphs_total} graphs' if graphs_total != b else ', median step time'
     return {'value': 1.0 / t_step, 'unit': 'rollout-steps/s', 'cores': cores, 'kind': 'port',
-            'sample': f'torch-CPU float64 oracle, {b} graphs x {args.cpu_sample_steps} rollout steps after 1 warm-up, '
-                      f'median step time scaled x{args.graphs / b:g} to {args.graphs} graphs'}
+            'sample': f'torch-CPU float64 oracle ({kind}), {b} graphs x {sample_steps} rollout steps after 1 warm-up{scaled}'}
 
 
-def main():
-    args = parse()
+class Workload:
+    """One rank's share of the batch, resident in HBM, and its rollout step."""
+
+    def __init__(self, args, mp, dev, n_graphs, seed):
+        import torch
+        from msmp_pde_amd.synthetic import make_case, EXPERIMENTS
+        self.eqv = dict(EXPERIMENTS[args.experiment])
+        cls = mp.MODEL_NAMES[args.model]
+        torch.manual_seed(0)                       # same weights on every rank
+        self.case = make_case(args.experiment, n_graphs, seed=seed, device=dev, dtype=torch.float32, neighbors=args.neighbors)
+        self.model = cls(self.case.pde, time_window=25, eq_variables=self.eqv, hidden_layer=6).to(dev).eval()
+        self.bsz = n_graphs
+        steps0 = [50] * n_graphs
+        data, labels = self.case.creator.create_data(self.case.u_super, steps0)
+        self.graph = self.case.creator.create_graph(data, labels, self.case.x, self.case.variables, steps0)
+        self.n_nodes, self.n_edges = self.graph.x.shape[0], self.graph.edge_index.shape[1]
+        self.pred = None
+        self.i = 0
+
+    def first(self):
+        self.pred = self.model(self.graph)
+
+    def step(self):
+        step = 75 + 25 * (self.i % 7)               # the reference unrolls steps 75..225 (train_helper.py:255)
+        self.i += 1
+        same = [step] * self.bsz
+        _, lab = self.case.creator.create_data(self.case.u_super, same)
+        g = self.case.creator.create_next_graph(self.graph, self.pred, lab, same)
+        self.pred = self.model(g)
+
+
+def timed_run(wl, D, torch, steps, warmup, preheat_s, before_timed=None, after_timed=None):
+    """W untimed warm-up steps, `preheat_s` seconds of further untimed steps (so that the timed window runs at the sustained,
+    power-limited clock and not at boost), then EXACTLY `steps` steps between barrier + synchronize brackets."""
+    with torch.no_grad():
+        wl.first()
+        for _ in range(warmup):
+            wl.step()
+        torch.cuda.synchronize()
+        t_heat, n_heat = time.perf_counter(), 0
+        while time.perf_counter() - t_heat < preheat_s:
+            for _ in range(4):
+                wl.step()
+            torch.cuda.synchronize()
+            n_heat += 4
+        if before_timed:
+            before_timed()
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.step()
+        torch.cuda.synchronize()
+        D.barrier()
+        elapsed = time.perf_counter() - t0
+        if after_timed:
+            after_timed()
+    return D.reduce_scalar(elapsed, 'max'), n_heat
+
+
+def run_rank(args):
     import torch
     import msmp_pde_amd as mp
     from msmp_pde_amd import dist as D, _lib
-    from msmp_pde_amd.synthetic import make_case, EXPERIMENTS
 
     rank, world, local = D.init_from_env(args.dist_backend)
-    local = local % max(torch.cuda.device_count(), 1)      # (testing) more ranks than GPUs: share devices
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+        return 2
+    if args.launcher_selftest:
+        seen = int(round(D.reduce_scalar(1, 'sum')))
+        blocks = [D.shard_range(args.graphs, r, world) for r in range(world)]
+        if rank == 0:
+            print(json.dumps({'ranks_seen': seen, 'n_gpus': world, 'shards': blocks}), flush=True)
+        return 0 if seen == args.gpus else 2
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback)'
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    local = local % max(torch.cuda.device_count(), 1)      # (testing) more ranks than GPUs: share devices
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     L = mp.lib()
@@ -115,127 +224,147 @@ def main():
     for kv in args.tune:
         k, v = kv.split('=')
         assert L.msmp_tune(k.encode(), int(v)) == 0, kv
+    ranks_seen = int(round(D.reduce_scalar(1, 'sum')))       # an all-reduce of 1 over RCCL: every rank is really there
+    if ranks_seen != args.gpus:
+        print(f'bench.py: {ranks_seen} ranks answered, --gpus {args.gpus}', file=sys.stderr)
+        return 2
 
-    exp = args.experiment
-    eqv = dict(EXPERIMENTS[exp])
-    cls = mp.MODEL_NAMES[args.model]
-    kind = cls.__name__
-    torch.manual_seed(0)                       # same weights on every rank
-    case = make_case(exp, args.graphs, seed=1000 + rank, device=dev, dtype=torch.float32, neighbors=args.neighbors)
-    model = cls(case.pde, time_window=25, eq_variables=eqv, hidden_layer=6).to(dev).eval()
-    bsz = args.graphs
-    steps0 = [50] * bsz
-    data, labels = case.creator.create_data(case.u_super, steps0)
-    graph = case.creator.create_graph(data, labels, case.x, case.variables, steps0)
-    n_nodes, n_edges = graph.x.shape[0], graph.edge_index.shape[1]
+    modes = ['strong', 'weak'] if args.scaling == 'strong' else ['weak', 'strong']
+    if world == 1 or args.no_extras:
+        modes = modes[:1]
+    results = {}
+    timing = {}
+    for mode in modes:
+        if mode == 'strong':
+            g0, g1 = D.shard_range(args.graphs, rank, world)
+            n_graphs = g1 - g0
+        else:
+            n_graphs = args.graphs
+        wl = Workload(args, mp, dev, n_graphs, seed=1000 + rank)
+        head = mode == modes[0]
 
-    def rollout_step(i, pred):
-        step = 75 + 25 * (i % 7)               # the reference unrolls steps 75..225 (train_helper.py:255)
-        same = [step] * bsz
-        _, lab = case.creator.create_data(case.u_super, same)
-        g = case.creator.create_next_graph(graph, pred, lab, same)
-        return model(g)
+        def start_events():
+            mask = 0b1111111 if args.time_all_kernels else (1 << _lib.K_EDGE_MLP) | (1 << _lib.K_NODE_PROJ)
+            L.msmp_timing_reset()
+            L.msmp_timing_enable(mask)
 
-    with torch.no_grad():
-        pred = model(graph)
-        for i in range(args.warmup):
-            pred = rollout_step(i, pred)
-        mask = 0b1111111 if args.time_all_kernels else (1 << _lib.K_EDGE_MLP) | (1 << _lib.K_NODE_PROJ)
-        L.msmp_timing_reset()
-        L.msmp_timing_enable(mask)
-        D.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            pred = rollout_step(args.warmup + i, pred)
-        torch.cuda.synchronize()
-        D.barrier()
-        elapsed = time.perf_counter() - t0
-        L.msmp_timing_enable(0)
-    finite = bool(torch.isfinite(pred).all().item())
-    elapsed = D.reduce_scalar(elapsed, 'max')
-    total_steps = D.reduce_scalar(args.steps, 'sum')
+        elapsed, n_heat = timed_run(wl, D, torch, args.steps if head else max(args.steps // 2, 5), args.warmup, args.preheat_s,
+                                    start_events if head else None, (lambda: L.msmp_timing_enable(0)) if head else None)
+        k_steps = args.steps if head else max(args.steps // 2, 5)
+        finite = bool(torch.isfinite(wl.pred).all().item())
+        graphs_all = int(round(D.reduce_scalar(n_graphs, 'sum')))
+        # strong: a step advances the ONE shared batch, so steps/s = K / t.  weak: every rank advances its own batch: N K / t.
+        value = k_steps / elapsed if mode == 'strong' else world * k_steps / elapsed
+        results[mode] = {'value': value, 'ms_per_step': elapsed / k_steps * 1e3, 'graphs_total': graphs_all, 'graphs_this_rank': n_graphs,
+                         'steps': k_steps, 'graph_steps_per_s': graphs_all * k_steps / elapsed, 'output_finite': finite, 'preheat_steps': n_heat}
+        if head:
+            timing = {'edge': _lib.timing_read(_lib.K_EDGE_MLP), 'proj': _lib.timing_read(_lib.K_NODE_PROJ),
+                      'n_nodes': wl.n_nodes, 'n_edges': wl.n_edges, 'model': wl.model, 'graph': wl.graph, 'steps': k_steps,
+                      'all': ({k: _lib.timing_read(k) for k in range(7)} if args.time_all_kernels else None)}
+            head_wl = wl
+        else:
+            del wl
+            torch.cuda.empty_cache()
 
     if rank != 0:
-        return
-    nv = len(eqv) + 1
+        return 0
+    head = results[modes[0]]
+    model, graph = timing['model'], timing['graph']
+    n_nodes, n_edges = timing['n_nodes'], timing['n_edges']
+    kind = type(model).__name__
+    exp = args.experiment
     k_msg = model.gnn_layers[0].message_net_1[0].in_features        # 2H + Tw + 1 + nv (Tw = 2*tw for the *2D classes)
     # Row L1 (message MLP) in the reference's dense formulation: 2*E*K_msg*H + 2*E*H*H per layer.
     flop_l1_dense = 2.0 * n_edges * k_msg * H + 2.0 * n_edges * H * H
-    # What the dominant kernel executes in the factorised form: message_net_2 only (message_net_1 became the
-    # per-node projections of node_proj_kernel: 2 * N * 2 * (H + 32*tail_chunks) * H).
+    # What the message kernel itself executes in the factorised form: message_net_2 only (message_net_1 became per-node projections).
     flop_edge_exec = 2.0 * n_edges * H * H
-    n_launch, ms_total = _lib.timing_read(_lib.K_EDGE_MLP)
-    n_proj, ms_proj = _lib.timing_read(_lib.K_NODE_PROJ)
+    n_launch, ms_total = timing['edge']
+    n_proj, ms_proj = timing['proj']
     t_launch = ms_total / max(n_launch, 1) * 1e-3
     t_proj = ms_proj / max(n_proj, 1) * 1e-3
     factorised = n_proj > 0
     flop_exec = flop_edge_exec if factorised else flop_l1_dense
     achieved = flop_exec / t_launch / 1e12 if n_launch else None
     alg_tflops = flop_l1_dense / (t_launch + t_proj) / 1e12 if n_launch else None
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')     # HBM bytes per launch from the rocprofv3 PMC passes
+    # HBM traffic of the dominant kernel: PMC passes of scripts/profile_gpu.sh, valid only for the sources and workload they were taken on
+    traffic, traffic_note = None, 'no profiles/traffic.json'
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = (tj.get('edge_mlp_kernel_occ4') or tj.get('edge_mlp_kernel_occ2') or tj.get('edge_mlp_kernel') or {}).get('hbm_bytes_per_launch')
-        except Exception:
-            traffic = None
-    # the split path's ceiling is the f16 matrix pipe doing 3 MFMAs per fp32 K-step; the fp32-MFMA path's is the fp32 peak
+            stamp = tj.get('_stamp', {})
+            want = {'source_hash': source_hash(), 'workload': f'{exp}/{args.model}/{head["graphs_this_rank"]}/n{args.neighbors}', 'split': int(split_path)}
+            sym = stamp.get('dominant_kernel')
+            if all(stamp.get(k) == v for k, v in want.items()) and sym in tj:
+                traffic = tj[sym].get('hbm_bytes_per_launch')
+                traffic_note = f'rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, kernel {sym}, profile {stamp.get("tag")}'
+            else:
+                traffic_note = f'profiles/traffic.json was taken on other sources / workload ({stamp}); not reported'
+        except Exception as exc:                        # noqa: BLE001
+            traffic_note = f'profiles/traffic.json unreadable: {exc}'
     peak_eq = PEAK_FP16_MFMA_TFLOPS / 3.0 if split_path else PEAK_FP32_MFMA_TFLOPS
+    # algorithmic HBM bytes of the fused message + mean launch (SURVEY 8d "fused layer" accounting for this kernel's share):
+    # read the node rows it consumes once, the CSR, write the aggregate
+    alg_bytes = (2 * n_nodes * H * 4 if n_proj > 0 else n_nodes * (H + k_msg - 2 * H) * 4) + n_edges * 8 + (n_nodes + 1) * 4 + n_nodes * H * 4
+    frac_mfma = (achieved / peak_eq) if achieved else None
+    frac_hbm = (alg_bytes / t_launch / 1e9 / PEAK_HBM_GBPS) if n_launch else None
     out = {
         'metric': 'rollout-steps/sec (whole node), E2 nx=100 tw=25',
-        'value': total_steps / elapsed, 'unit': 'rollout-steps/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'{exp} {args.model} ({kind}), {bsz} graphs/GPU x nx=100, time_window=25, '
-                               f'{"6 gated layer pairs" if model.GATED else "6 layers"}, '
-                               f'{"radius graph n=" if exp in ("E2", "MSWG3") else "knn graph k="}{args.neighbors}', 'graphs_per_gpu': bsz, 'nodes': n_nodes,
-                   'edges': n_edges, 'parallelism': f'dp{world} (graph-sharded, no collective in the rollout)',
-                   'graph_steps_per_s': total_steps * bsz / elapsed, 'output_finite': finite},
-        # `achieved` counts the fp32 GEMM FLOPs the dominant kernel computes (conservative: the factorised form
-        # removed 69 % of row L1's dense FLOPs).  The kernel evaluates them on the fp16 matrix pipe (2-way fp16 split
-        # of both operands, 3 MFMAs per K=16 step, fp32-class accuracy), so `peak` is that pipe's dense peak / 3 and
-        # `frac` equals the literal f16-MFMA utilisation (`matrix_pipe`); `vs_fp32_mfma_peak` prices the same FLOPs
-        # against what an fp32-MFMA implementation could reach at best (it exceeds 1).  `algorithmic` prices row L1 (node_proj + edge kernels) at SURVEY 8d's dense figure.
-        'roofline': {'bound': 'mfma', 'kernel': 'edge_mlp_kernel (message_net_2 + Swish + per-target mean'
+        'value': head['value'], 'unit': 'rollout-steps/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True,
+        'scaling': modes[0], 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'ranks_seen': ranks_seen,
+        'config': {'workload': f'{exp} {args.model} ({kind}), {head["graphs_total"]} graphs x nx=100, time_window=25, '
+                               f'{"6 gated layer pairs" if getattr(model, "GATED", False) else "6 layers"}, '
+                               f'{"radius graph n=" if exp in ("E2", "MSWG3") else "knn graph k="}{args.neighbors}',
+                   'graphs_total': head['graphs_total'], 'graphs_per_gpu': head['graphs_this_rank'], 'nodes_per_gpu': n_nodes, 'edges_per_gpu': n_edges,
+                   'parallelism': f'dp{world} (graph-sharded, no collective in the rollout)',
+                   'graph_steps_per_s': head['graph_steps_per_s'], 'output_finite': head['output_finite'],
+                   'preheat': f'{head["preheat_steps"]} untimed steps (>= {args.preheat_s:g} s) after the {args.warmup} warm-up steps'},
+        # `achieved` counts the fp32 GEMM FLOPs the dominant kernel computes (the factorised form removed 69 % of row L1's dense
+        # FLOPs).  They execute on the fp16 matrix pipe (2-way fp16 split of both operands, 3 MFMAs per K=16 step, fp32-class
+        # accuracy), so `peak` is that pipe's dense peak / 3 and `frac` equals the literal f16-MFMA utilisation (`matrix_pipe`).
+        # `bound` names the nearer of the two rooflines; `bound_detail` says what the phase profile shows actually limits it.
+        'roofline': {'bound': 'mfma' if (frac_mfma or 0) >= (frac_hbm or 0) else 'hbm',
+                     'bound_detail': 'neither roof: see DESIGN.md section 4 (phase profile: node-row gather latency, LDS port and activation VALU; matrix pipe and HBM both under 0.4)',
+                     'kernel': 'edge message kernel (message_net_2 + Swish + per-target mean'
                      + (', factorised message_net_1' if factorised else ', dense message_net_1')
                      + ('; fp32 GEMM on the fp16 matrix pipe via 2-way fp16 split)' if split_path else '; fp32 MFMA)'),
                      'achieved': achieved, 'peak': peak_eq,
-                     'unit': 'TFLOP/s', 'frac': (achieved / peak_eq) if achieved else None,
+                     'unit': 'TFLOP/s', 'frac': frac_mfma,
                      'peak_note': ('fp32-equivalent peak of the 3-MFMA fp16 split = dense f16 MFMA peak / 3' if split_path
                                    else 'dense fp32 MFMA peak'),
                      'vs_fp32_mfma_peak': (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None,
-                     'traffic': traffic, 'launches': n_launch, 'avg_launch_ms': t_launch * 1e3,
+                     'hbm': {'algorithmic_bytes_per_launch': alg_bytes, 'achieved_GBps': alg_bytes / t_launch / 1e9 if n_launch else None,
+                             'peak_GBps': PEAK_HBM_GBPS, 'frac': frac_hbm},
+                     'traffic': traffic, 'traffic_note': traffic_note, 'launches': n_launch, 'avg_launch_ms': t_launch * 1e3,
                      'executed_gflop_per_launch': flop_exec / 1e9,
                      'matrix_pipe': ({'dtype': 'f16 (3 MFMAs per fp32 K=16 step)', 'executed_tflops': 3 * achieved,
                                       'peak_tflops': PEAK_FP16_MFMA_TFLOPS, 'frac': 3 * achieved / PEAK_FP16_MFMA_TFLOPS}
                                      if split_path and achieved else None),
-                     'algorithmic': {'row': 'L1+L2 message MLP + mean = node_proj_kernel + edge_mlp_kernel per layer',
+                     'algorithmic': {'row': 'L1+L2 message MLP + mean = node projection + message kernels per layer',
                                      'gflop_per_layer': flop_l1_dense / 1e9, 'ms_per_layer': (t_launch + t_proj) * 1e3,
                                      'tflops': alg_tflops, 'frac': alg_tflops / PEAK_FP32_MFMA_TFLOPS if alg_tflops else None},
-                     'share_of_step': (ms_total / args.steps) / (elapsed / args.steps * 1e3) if n_launch else None},
+                     'share_of_step': (ms_total / timing['steps']) / head['ms_per_step'] if n_launch else None},
     }
-    if args.time_all_kernels:
-        names = {_lib.K_SCATTER_MEAN: 'scatter_mean', _lib.K_NODE_UPDATE: 'node_update', _lib.K_NORM: 'norm_blend',
+    if len(modes) > 1:
+        other = results[modes[1]]
+        out[modes[1]] = {'value': other['value'], 'unit': 'rollout-steps/s', 'ms_per_step': other['ms_per_step'], 'steps': other['steps'],
+                         'graphs_total': other['graphs_total'], 'graphs_per_gpu': other['graphs_this_rank'],
+                         'graph_steps_per_s': other['graph_steps_per_s'],
+                         'note': ('every rank advances its own 2048-graph batch; value = N x steps / max time' if modes[1] == 'weak'
+                                  else 'the 2048-graph batch split over the ranks; value = steps / max time')}
+    if args.time_all_kernels and timing['all']:
+        names = {_lib.K_EDGE_MLP: 'edge_mlp', _lib.K_SCATTER_MEAN: 'scatter_mean', _lib.K_NODE_UPDATE: 'node_update', _lib.K_NORM: 'norm_blend',
                  _lib.K_LEM: 'lem_encoder', _lib.K_NODE_PROJ: 'node_project', _lib.K_DECODER: 'decoder'}
-        out['kernels_ms_per_step'] = {'edge_mlp': ms_total / args.steps}
-        for k, nm in names.items():
-            n_k, ms_k = _lib.timing_read(k)
-            out['kernels_ms_per_step'][nm] = ms_k / args.steps
-        n_sc, ms_sc = _lib.timing_read(_lib.K_SCATTER_MEAN)
-        if n_sc:
-            sc_bytes = n_edges * H * 4 + n_edges * 0 + (n_nodes + 1) * 4 + n_nodes * H * 4
-            out['scatter_hbm'] = {'achieved_GBps': sc_bytes / (ms_sc / n_sc * 1e-3) / 1e9, 'peak_GBps': 8000.0,
-                                  'algorithmic_bytes_per_launch': sc_bytes}
-    if rank == 0 and 'scatter_hbm' not in out:
+        out['kernels_ms_per_step'] = {nm: timing['all'][k][1] / timing['steps'] for k, nm in names.items()}
+        out['kernels_launches_per_step'] = {nm: timing['all'][k][0] / timing['steps'] for k, nm in names.items()}
+    if not args.no_extras:
         # row L2 standalone ("HBM GB/s on the scatter"): the default layer path fuses the mean into the message kernel,
         # so the CSR segmented-mean kernel is timed here on a message tensor of the workload's size, outside the timed region
         from msmp_pde_amd.graph import structure_of
         gs = structure_of(graph)
         msg = torch.randn(n_edges, H, device=dev)
         agg = torch.empty(n_nodes, H, device=dev)
-        L = _lib.lib()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for i in range(23):
             if i == 3:
@@ -246,13 +375,39 @@ def main():
         sc_ms = ev0.elapsed_time(ev1) / 20
         sc_bytes = n_edges * H * 4 + (n_nodes + 1) * 4 + n_nodes * H * 4
         out['scatter_hbm'] = {'kernel': 'scatter_mean_kernel (standalone row L2; fused into the message kernel on the default path)',
-                              'achieved_GBps': sc_bytes / (sc_ms * 1e-3) / 1e9, 'peak_GBps': 8000.0,
-                              'frac': sc_bytes / (sc_ms * 1e-3) / 1e9 / 8000.0, 'algorithmic_bytes_per_launch': sc_bytes,
+                              'achieved_GBps': sc_bytes / (sc_ms * 1e-3) / 1e9, 'peak_GBps': PEAK_HBM_GBPS,
+                              'frac': sc_bytes / (sc_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 'algorithmic_bytes_per_launch': sc_bytes,
                               'avg_launch_ms': sc_ms}
         del msg, agg
+    if world == 1 and not args.no_extras:
+        # BASELINE.json configs[0]: E2 MP-PDE on 32 graphs (the reference's own CPU-runnable case), HIP path and CPU port
+        a0 = parse(['--model', 'MP-PDE', '--experiment', 'E2', '--graphs', '32'])
+        wl0 = Workload(a0, mp, dev, 32, seed=1000)
+        el0, _ = timed_run(wl0, D, torch, 50, 5, 0.2)
+        out['config0'] = {'workload': 'E2 MP-PDE (MP_PDE_Solver), 32 graphs (BASELINE.json configs[0])',
+                          'value': 50 / el0, 'unit': 'rollout-steps/s', 'ms_per_step': el0 / 50 * 1e3}
+        if not args.no_cpu_baseline:
+            out['config0']['cpu_baseline'] = cpu_baseline('MP-PDE', 'E2', 32, 32, 5)
+        del wl0
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
-        out['cpu_baseline'] = cpu_baseline(args, kind, eqv)
+        out['cpu_baseline'] = cpu_baseline(args.model, exp, args.graphs, args.cpu_sample_graphs, args.cpu_sample_steps, args.neighbors)
     print(json.dumps(out), flush=True)
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and not os.environ.get('WORLD_SIZE'):
+        sys.exit(launch_children(args, argv))         # before any GPU call in this process
+    rc = run_rank(args)
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:                                  # noqa: BLE001
+        pass
+    sys.exit(rc)
 
 
 if __name__ == '__main__':

@@ -5,7 +5,7 @@ import os
 from ctypes import c_int, c_int64, c_size_t, c_void_p, c_float, c_double, c_char_p
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, 'libmsmp_pde.so')
+LIB_PATH = os.environ.get('MSMP_LIB_PATH') or os.path.join(PKG, 'libmsmp_pde.so')     # MSMP_LIB_PATH: a diagnostic build of the same library
 
 MSMP_LAYER_RESIDUAL_SWISH = 0
 MSMP_LAYER_LIN = 1

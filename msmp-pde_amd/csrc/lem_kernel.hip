@@ -543,10 +543,10 @@ __global__ __launch_bounds__(512, 2) void lem_encoder_split2_kernel(LemSplitArgs
         __syncthreads();                                                                               \
     }
     // sigmoid(x 2^-s) = 1 / (1 + 2^(c x)),  tanh(x 2^-s) = sign(x) (1 - e) / (1 + e), e = 2^(c2 |x|)
-    auto sig = [](float x, float cc) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * cc)); };
+    auto sig = [](float x, float cc) { return msmp_rcp(1.0f + msmp_exp2(x * cc)); };
     auto tnh = [](float x, float c2) {
-        const float e = __builtin_amdgcn_exp2f(fabsf(x) * c2);
-        return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+        const float e = msmp_exp2(fabsf(x) * c2);
+        return copysignf((1.0f - e) * msmp_rcp(1.0f + e), x);
     };
     const float* wfb = a.wx + lane + (size_t)tile0 * 4 * 64;
 
@@ -784,8 +784,8 @@ __device__ __forceinline__ void lem_ws_update_publish(const f32x16& a0, const f3
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            ea[jj] = f32x2{__builtin_amdgcn_exp2f(ta[jj][0]), __builtin_amdgcn_exp2f(ta[jj][1])};
-            eb[jj] = f32x2{__builtin_amdgcn_exp2f(tb[jj][0]), __builtin_amdgcn_exp2f(tb[jj][1])};
+            ea[jj] = f32x2{msmp_exp2(ta[jj][0]), msmp_exp2(ta[jj][1])};
+            eb[jj] = f32x2{msmp_exp2(tb[jj][0]), msmp_exp2(tb[jj][1])};
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -795,7 +795,7 @@ __device__ __forceinline__ void lem_ws_update_publish(const f32x16& a0, const f3
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) rr[jj] = f32x2{__builtin_amdgcn_rcpf(q[jj][0]), __builtin_amdgcn_rcpf(q[jj][1])};
+        for (int jj = 0; jj < 4; ++jj) rr[jj] = f32x2{msmp_rcp(q[jj][0]), msmp_rcp(q[jj][1])};
         f32x2 tt[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {

@@ -50,6 +50,9 @@ __host__ __device__ inline LemLayout lem_layout() {
 }
 
 __device__ __forceinline__ float tanhf_(float x) {
+#if MSMP_PRECISE_ACT
+    return tanhf(x);
+#endif
     // (1 - e^{-2|x|}) / (1 + e^{-2|x|}) with the sign restored; absolute error ~1e-7
     const float t = __builtin_amdgcn_exp2f(fabsf(x) * -2.88539008177792681472f);
     const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);

@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void tile_t_instance_norm(f32x16 (&x)[4], int wave, i
     tile_t_total(s, part, tot, tid, wave, c, hh, m);
 #pragma unroll
     for (int T = 0; T < 4; ++T) {
-        const float f = unit * __builtin_amdgcn_rsqf(m[T] * inv * unit * unit + eps);
+        const float f = unit * msmp_rsq(m[T] * inv * unit * unit + eps);
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[T][r] *= f;
     }

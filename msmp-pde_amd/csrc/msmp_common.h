@@ -74,6 +74,18 @@ __host__ __device__ inline PackedLayout packed_layout(int tw, int nv) {
 
 // Swish(x) = x * sigmoid(x) (experiments/models_gnn.py:20-21) = x / (1 + 2^(-x*log2 e)).
 // v_exp_f32 and v_rcp_f32 are 1-ulp; measured against the float64 oracle in tests/test_gpu_kernels.py.
+// MSMP_PRECISE_ACT (diagnostic build, `MSMP_PRECISE=1 python msmp-pde_amd/build.py`): correctly-rounded division and libm exp /
+// tanh / sqrt everywhere, to attribute the full-depth error of the network to the activation approximations or to the GEMMs.
+#if MSMP_PRECISE_ACT
+__device__ __forceinline__ float msmp_rcp(float x) { return __fdiv_rn(1.0f, x); }
+__device__ __forceinline__ float msmp_exp2(float x) { return exp2f(x); }
+__device__ __forceinline__ float msmp_rsq(float x) { return __fdiv_rn(1.0f, __fsqrt_rn(x)); }
+__device__ __forceinline__ float swishf(float x) { return __fdiv_rn(x, 1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __fdiv_rn(1.0f, 1.0f + expf(-x)); }
+#else
+__device__ __forceinline__ float msmp_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float msmp_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float msmp_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float swishf(float x) {
     const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896340736f);
     return x * __builtin_amdgcn_rcpf(1.0f + e);
@@ -82,6 +94,7 @@ __device__ __forceinline__ float sigmoidf_(float x) {
     const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896340736f);
     return __builtin_amdgcn_rcpf(1.0f + e);
 }
+#endif
 
 // Row of a 32x32 MFMA accumulator register: D[row][col = lane & 31].
 __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }

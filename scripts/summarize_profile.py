@@ -65,5 +65,17 @@ for k in sorted(set(fetch) | set(write)):
     lines.append(f'| `{short}` | {len(fetch.get(k, []))} | {fm:.0f} | {rb:.3e} | {wm:.0f} | {wb:.3e} | {rb + wb:.3e} |')
 open(os.path.join(dst, f'{tag}_summary.md'), 'w').write('\n'.join(lines) + '\n')
 if traffic:
+    # stamp: bench.py reports `roofline.traffic` only when the kernel sources, the workload and the matrix path are the ones
+    # these counters were taken on (no silent staleness)
+    sys.path.insert(0, ROOT)
+    import bench as _bench
+    cfg = bench.get('config', {}) if bench else {}
+    dominant = max((r for r in rows if 'msmp::' in r['Name'] and 'edge' in r['Name']), key=lambda r: float(r['TotalDurationNs']), default=None)
+    dom_short = dominant['Name'].replace('void ', '').replace('msmp::', '').split('<')[0].split('(')[0] if dominant else None
+    stamp_file = os.path.join(src, 'stamp.json')
+    stamp = json.load(open(stamp_file)) if os.path.exists(stamp_file) else {}
+    stamp.update({'tag': tag, 'dominant_kernel': dom_short})
+    stamp.setdefault('source_hash', _bench.source_hash())
+    traffic['_stamp'] = stamp
     json.dump(traffic, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
 print('\n'.join(lines))

@@ -19,6 +19,12 @@ Fixtures written:
   layer_{GNN_Layer,GNN_LayerLin}.npz   one message-passing layer: inputs, weights, pre-/post-norm out
   solver_{MP_PDE_Solver,MP_PDE_SolverGated,MP_PDE_Solver2D,MP_PDE_Solver2DGated}.npz
                                  state_dict + graph batch + forward output (+ 3-step rollout for E2)
+  deep_{class}_{experiment}.npz  FULL-DEPTH (hidden_layer = 6, the reference's default) forward + one rollout step of the
+                                 LEM-free classes; the 0.6-1.3 M parameters are not stored but re-created from
+                                 seeded_weights.seeded_state_dict (same function in the tests), so a fixture is ~100 KB
+
+    python tests/golden/gen_golden.py            # everything
+    python tests/golden/gen_golden.py deep       # only the full-depth fixtures
 """
 import os
 import sys
@@ -246,8 +252,55 @@ def gen_solvers(rng):
         print(name, exp, 'params', sum(p.numel() for p in model.parameters()), 'out max', float(pred.abs().max()))
 
 
+DEEP_CASES = [('MP_PDE_Solver', 'E2', 1), ('MP_PDE_SolverGated', 'E2', 1), ('MP_PDE_SolverGated', 'WE3', 1),
+              ('MP_PDE_Solver2DGated', 'MSWG3', 0), ('MP_PDE_Solver2DGated', 'RPU', 0)]
+
+
+def gen_deep():
+    """Full-depth fixtures: the reference's classes at hidden_layer = 6 with seeded parameters."""
+    sys.path.insert(0, HERE)
+    from seeded_weights import seeded_state_dict
+    rng = np.random.default_rng(20261005)
+    for idx, (name, exp, n_roll) in enumerate(DEEP_CASES):
+        cls = getattr(M2 if '2D' in name else M, name)
+        bsz = 4
+        pde, creator, u, x, variables, eqv = make_case(exp, rng, bsz)
+        model = cls(pde, time_window=TW, eq_variables=eqv, hidden_layer=6)
+        seed = 7000 + idx
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        sd = seeded_state_dict(shapes, seed)
+        model.load_state_dict({k: torch.tensor(v.astype(np.float64)) for k, v in sd.items()}, strict=True)
+        model.eval()
+        steps = [50] * bsz
+        g, ut = build_graph(creator, u, x, variables, steps)
+        d = {'experiment': exp, 'hidden_layer': 6, 'weights_seed': seed, 'u_super': u[:, :50 + TW * (n_roll + 2)], 'x_grid': x,
+             'tmin': pde.tmin, 'tmax': pde.tmax, 'dt': pde.dt, 'L': float(pde.L), 'steps': np.array(steps),
+             'param_names': np.array(list(shapes.keys())), 'param_shapes': np.array([','.join(str(n) for n in s) for s in shapes.values()]),
+             'param_checksum': np.float64(sum(float(np.abs(v.astype(np.float64)).sum()) for v in sd.values()))}
+        d.update({'var_' + k: v for k, v in variables.items()})
+        d.update(graph_to_np(g, 'g_'))
+        with torch.no_grad():
+            pred = model(g)
+            d['out'] = pred.numpy().copy()
+            step = 50
+            for r in range(n_roll):
+                step += TW
+                same = [step] * bsz
+                _, labels = creator.create_data(ut, same)
+                g = creator.create_next_graph(g, pred, labels, same)
+                pred = model(g)
+                d[f'roll{r}'] = pred.numpy().copy()
+        d['n_roll'] = n_roll
+        save(os.path.join(HERE, f'deep_{name}_{exp}.npz'), d)
+        print('deep', name, exp, 'params', sum(p.numel() for p in model.parameters()), 'out max', float(pred.abs().max()))
+
+
 if __name__ == '__main__':
-    rng = np.random.default_rng(20261004)
-    gen_graphs(rng)
-    gen_layers(rng)
-    gen_solvers(rng)
+    if len(sys.argv) > 1 and sys.argv[1] == 'deep':
+        gen_deep()
+    else:
+        rng = np.random.default_rng(20261004)
+        gen_graphs(rng)
+        gen_layers(rng)
+        gen_solvers(rng)
+        gen_deep()

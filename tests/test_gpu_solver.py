@@ -6,11 +6,12 @@ import pytest
 import torch
 
 from oracle import msmp_oracle as O
-from helpers import load, sd_of, graph_of, pde_of, EXPERIMENTS, synthetic_case
+from helpers import (load, sd_of, graph_of, pde_of, EXPERIMENTS, synthetic_case, DEEP_CASES, deep_state_dict, assert_parity, record_parity,
+                     err_stats)
 
 pytestmark = pytest.mark.gpu
 TW = 25
-TOL = 1e-5      # BASELINE.json north_star: "fp32 node output within 1e-5 of the CPU reference"
+TOL = 1e-5      # BASELINE.json north_star: "fp32 node output within 1e-5 of the CPU reference"; full-network bar: helpers.assert_parity
 
 
 @pytest.fixture(scope='module')
@@ -45,7 +46,7 @@ def test_solver_golden_forward_and_rollout(mp, kind):
     d = load(f'solver_{kind}.npz')
     exp = str(d['experiment'])
     pde, pde_name, eqv = make_pde(mp, exp, d)
-    layers = int(d['hidden_layer'])
+    layers_n = layers = int(d['hidden_layer'])
     model = getattr(mp, kind)(pde, time_window=TW, eq_variables=eqv, hidden_layer=layers)
     # reference state_dict loads by name: key set and shapes must be identical
     missing = model.load_state_dict({k: torch.tensor(v) for k, v in sd_of(d).items()}, strict=True)
@@ -71,6 +72,8 @@ def test_solver_golden_forward_and_rollout(mp, kind):
     err_dense = np.abs(out_dense.double().cpu().numpy() - d['out']).max()
     print(f'{kind}: max|hip - reference| = {err:.3e} (default: factorised + fp16-split), {err_f32:.3e} (fp32 MFMA), '
           f'{err_dense:.3e} (fp32 MFMA, dense message_net_1)')
+    record_parity('solver_golden_forward', f'{kind}/{exp}/depth{layers_n}', max_abs=err, rms=err_stats(out.double().cpu().numpy(), d['out'])[1],
+                  max_abs_fp32_mfma=err_f32, max_abs_fp32_mfma_dense=err_dense, bar_max=TOL, reference='reference class output (golden)')
     assert err < TOL and err_f32 < TOL and err_dense < TOL, (err, err_f32, err_dense)
 
     n_roll = int(d['n_roll'])
@@ -88,11 +91,45 @@ def test_solver_golden_forward_and_rollout(mp, kind):
                 pred = model(data)
             err = np.abs(pred.double().cpu().numpy() - d[f'roll{r}']).max()
             print(f'{kind}: rollout step {r}: {err:.3e}')
+            record_parity('solver_golden_rollout', f'{kind}/{exp}/step{r}', max_abs=err, bar_max=TOL, reference='reference class output (golden)')
             assert err < TOL, (r, err)
+
+
+@pytest.mark.parametrize('kind,exp', DEEP_CASES)
+def test_full_depth_vs_reference_golden(mp, kind, exp):
+    """Full depth (hidden_layer = 6: six layers / six gated pairs, the reference's default) against the output of the REFERENCE's
+    own class (tests/golden/deep_*.npz; parameters re-created from the fixture's seed, names / order / shapes checked against
+    the drop-in class's state_dict): forward and one unrolled step.  Bar: helpers.assert_parity."""
+    d = load(f'deep_{kind}_{exp}.npz')
+    pde, pde_name, eqv = make_pde(mp, exp, d)
+    model = getattr(mp, kind)(pde, time_window=TW, eq_variables=eqv, hidden_layer=6)
+    sd = deep_state_dict(d, {k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
+    model.cuda().eval()
+    g = graph_of(d)
+    data = to_data(mp, g)
+    sd64 = {k: v.astype(np.float64) for k, v in sd.items()}
+    opde = pde_of(d)
+    with torch.no_grad():
+        out = model(data)
+    floor = O.solver_forward(kind, sd64, g, opde, TW, eqv, 6, dtype=np.float32)
+    assert_parity('full_depth_vs_reference_golden', f'{kind}/{exp}', out.double().cpu().numpy(), d['out'], floor)
+    if int(d['n_roll']):
+        gc = mp.GraphCreator(pde, neighbors=3, time_window=TW, device='cuda')
+        u = torch.tensor(d['u_super'].astype(np.float64)).cuda()
+        same = [50 + TW] * u.shape[0]
+        _, labels = gc.create_data(u, same)
+        data = gc.create_next_graph(data, out, labels, same)
+        with torch.no_grad():
+            pred = model(data)
+        # the float32 floor of the second step: the float32 oracle rolled out from ITS OWN first prediction
+        preds32 = O.rollout(kind, sd64, g, pde_name, opde, TW, eqv, 6, d['u_super'].astype(np.float64), 50, 1, dtype=np.float32)
+        assert_parity('full_depth_vs_reference_golden', f'{kind}/{exp}/rollout1', pred.double().cpu().numpy(), d['roll0'], preds32[1])
 
 
 @pytest.mark.parametrize('kind,exp', [('MP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'E2'),
                                       ('MP_PDE_SolverLEMLinGated', 'E2'), ('MP_PDE_SolverGated', 'WE3'),
+                                      ('MP_PDE_SolverLEMLinGated', 'WE3'),
                                       ('MP_PDE_Solver2DLEMLinGated', 'RPU'), ('MP_PDE_Solver2DGated', 'MSWG3'),
                                       ('MP_PDE_SolverLEMLin', 'E2'), ('MP_PDE_Solver2DLEMLin', 'MSWG3'),
                                       ('MP_PDE_Solver2DLEMLinG2', 'RPU'), ('MSSMP_PDE_Solver', 'E2'),
@@ -113,16 +150,8 @@ def test_full_depth_vs_oracle(mp, kind, exp):
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     g = case.graph_np()
     ref = O.solver_forward(kind, sd, g, case.pde, TW, case.eqv, 6)
-    err = np.abs(out.double().cpu().numpy() - ref).max()
-    # The bar is 1e-5.  An untrained 12-layer gated stack is ill-conditioned (each InstanceNorm divides
-    # by a small per-graph std; measured growth ~2x per layer), so for some configurations ANY float32
-    # evaluation is further than 1e-5 from float64.  The floor is measured, not assumed: the same oracle
-    # run in float32.  The HIP path must be inside 1e-5 wherever float32 can be, and never worse than
-    # 8x the float32 floor (max-abs over ~1e5 outputs is an outlier statistic; DESIGN.md "Numerics").
-    floor = np.abs(O.solver_forward(kind, sd, g, case.pde, TW, case.eqv, 6, dtype=np.float32).astype(np.float64) - ref).max()
-    rms = np.sqrt(np.mean((out.double().cpu().numpy() - ref) ** 2))
-    print(f'{kind}/{exp}: depth 6, max|hip - oracle| = {err:.3e} (rms {rms:.2e}), float32-oracle floor = {floor:.3e}')
-    assert err < max(TOL, 8 * floor), (err, floor)
+    floor = O.solver_forward(kind, sd, g, case.pde, TW, case.eqv, 6, dtype=np.float32)
+    assert_parity('full_depth_vs_oracle', f'{kind}/{exp}', out.double().cpu().numpy(), ref, floor)     # bar: helpers.assert_parity
 
 
 def test_graph_sharding_is_exact(mp):
@@ -244,10 +273,9 @@ def test_large_neighbourhood_stress_vs_oracle(mp, neighbors):
     from types import SimpleNamespace
     g = SimpleNamespace(**{k: v.detach().cpu().numpy() for k, v in graph.__dict__.items() if torch.is_tensor(v)})
     ref = O.solver_forward('MP_PDE_Solver2DLEMLinGated', sd, g, c.pde, TW, c.eqv, 2)
-    floor = np.abs(O.solver_forward('MP_PDE_Solver2DLEMLinGated', sd, g, c.pde, TW, c.eqv, 2, dtype=np.float32).astype(np.float64) - ref).max()
-    err = np.abs(out.double().cpu().numpy() - ref).max()
-    print(f'n={neighbors}: E/graph {ei_ref.shape[1] // 6}, max in-degree {deg.max()}, max|hip - oracle| = {err:.3e}, fp32 floor {floor:.3e}')
-    assert err < max(TOL, 8 * floor), (err, floor)
+    floor = O.solver_forward('MP_PDE_Solver2DLEMLinGated', sd, g, c.pde, TW, c.eqv, 2, dtype=np.float32)
+    print(f'n={neighbors}: E/graph {ei_ref.shape[1] // 6}, max in-degree {deg.max()}')
+    assert_parity('large_neighbourhood_stress', f'MSWG3/n={neighbors}', out.double().cpu().numpy(), ref, floor)
 
 
 @pytest.mark.parametrize('nx', [40, 200])
@@ -269,12 +297,10 @@ def test_other_grid_resolutions_vs_oracle(mp, nx):
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     g = SimpleNamespace(**{k: v.detach().cpu().numpy() for k, v in graph.__dict__.items() if torch.is_tensor(v)})
     ref = O.solver_forward(kind, sd, g, c.pde, TW, c.eqv, 2)
-    floor = np.abs(O.solver_forward(kind, sd, g, c.pde, TW, c.eqv, 2, dtype=np.float32).astype(np.float64) - ref).max()
+    floor = O.solver_forward(kind, sd, g, c.pde, TW, c.eqv, 2, dtype=np.float32)
     with torch.no_grad():
         out = model.eval()(graph)
-    err = np.abs(out.double().cpu().numpy() - ref).max()
-    print(f'nx={nx}: max|hip - oracle| = {err:.3e}, fp32 floor {floor:.3e}')
-    assert err < max(TOL, 8 * floor), (err, floor)
+    assert_parity('other_grid_resolutions', f'{kind}/E2/nx={nx}', out.double().cpu().numpy(), ref, floor)
     # gradients on the same batch
     model.train()
     loss = torch.sqrt(((model(graph) - graph.y) ** 2).sum())

@@ -26,7 +26,7 @@ def mp():
 @pytest.mark.parametrize('kind,exp', [('MP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'E2'), ('MP_PDE_Solver2DGated', 'RPU'),
                                       ('MP_PDE_SolverLEMLinGated', 'E2'), ('MP_PDE_Solver2DLEMLinGated', 'RPU'),
                                       ('MP_PDE_SolverLEMLin', 'E2'), ('MP_PDE_Solver2DLEMLinG2', 'RPU'),
-                                      ('MSSMP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'WE3'),
+                                      ('MSSMP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'WE3'), ('MP_PDE_SolverLEMLinGated', 'WE3'),
                                       ('MP_PDE_Solver2DLEMLinGated', 'MSWG3'), ('MP_PDE_Solver2D', 'RPU'),
                                       ('MP_PDE_SolverLSTMLinGated', 'E2'), ('MP_PDE_Solver2DLSTMLin', 'RPU')])
 def test_gradients_match_float64_oracle(mp, kind, exp):

@@ -197,3 +197,23 @@ def test_sharding_two_ranks_gloo():
         assert ok
         assert n_nodes == full_n and n_edges == full_e
         assert t_max == 2.0
+
+
+def test_bench_launcher_starts_one_rank_per_gpu():
+    """`python bench.py --gpus N` without a torchrun environment must start N ranks itself: the parent
+    spawns N children with RANK / WORLD_SIZE / MASTER_* set, they join a gloo group and an all-reduce of 1 counts N; with a
+    torchrun-style environment whose WORLD_SIZE disagrees with --gpus the run fails non-zero."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo', '--launcher-selftest',
+                        '--graphs', '2048'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['ranks_seen'] == 2 and out['n_gpus'] == 2
+    assert out['shards'] == [[0, 1024], [1024, 2048]]
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29999')
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launcher-selftest'], env=env2,
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and 'WORLD_SIZE=1' in r2.stderr

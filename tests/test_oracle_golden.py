@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import msmp_oracle as O
-from helpers import load, sd_of, graph_of, pde_of, EXPERIMENTS
+from helpers import load, sd_of, graph_of, pde_of, EXPERIMENTS, DEEP_CASES, deep_state_dict
 
 TW = 25
 TOL = 1e-12
@@ -129,3 +129,23 @@ def test_lem_cell_properties():
     assert np.all(O.lem_forward(x, w, wz, b, bz, dt=0.0) == 0)
     y = O.lem_forward(x, w, wz, b, bz, dt=1.0)
     assert y.shape == (n, nh) and np.all(np.abs(y) <= 1.0)
+
+
+@pytest.mark.parametrize('kind,exp', DEEP_CASES)
+def test_full_depth_solver_vs_reference(kind, exp):
+    """Full depth (hidden_layer = 6, the reference's default): the oracle against the output of the REFERENCE's class with the
+    same seeded parameters (tests/golden/deep_*.npz), forward and one unrolled step."""
+    d = load(f'deep_{kind}_{exp}.npz')
+    pde_name, eqv, unstructured = EXPERIMENTS[exp]
+    pde = pde_of(d)
+    g = graph_of(d)
+    sd = {k: v.astype(np.float64) for k, v in deep_state_dict(d).items()}
+    out = O.solver_forward(kind, sd, g, pde, TW, eqv, 6)
+    err = np.abs(out - d['out']).max()
+    assert err < 1e-9 * max(1.0, np.abs(d['out']).max()), err
+    n_roll = int(d['n_roll'])
+    if n_roll:
+        u = d['u_super'].astype(np.float64)
+        preds = O.rollout(kind, sd, g, pde_name, pde, TW, eqv, 6, u, 50, n_roll)
+        for r in range(n_roll):
+            assert np.abs(preds[r + 1] - d[f'roll{r}']).max() < 1e-8 * max(1.0, np.abs(d[f'roll{r}']).max()), r
