@@ -62,6 +62,8 @@ const char* msmp_last_error(void);
  *   "edge_xcd" 1: workgroup b of the fused message kernels takes tile (b % 8) * ceil(tiles / 8) + b / 8, i.e. consecutive tiles on
  *             one XCD (measured: no effect, the tiles share too little); 0 (default): tile b.
  *   "edge_ws" 1: persistent weight-stationary message + mean kernel (max in-degree <= 32); 0 (default): streamed weights.
+ *   "tile"    2 (default): with node tiles, project P / Q inside the message kernel; 1: msmp_node_project_f32 + tile kernel on the
+ *             staged P / Q rows; 0: ignore the tiles (gather kernels).
  *   "tail"    1 (default): msmp_mp_layer_f32 uses msmp_node_tail_f32 for graphs of up to 128 nodes; 0: the piecewise kernels.
  *   "pair"    gated pair: both heads' projection / message kernels in one launch each (bit-identical results): 0 never,
  *             1 (default) for batches of up to 65 536 nodes, where a step is bound by the latency of its ~60 dependent launches, 2 always.
@@ -151,6 +153,36 @@ int msmp_edge_aggregate_projected_f32(const float* p, const float* q, const int3
                                       int64_t n_edges, int max_in_degree, int tw, int nv,
                                       const float* packed, float* agg_out, msmp_stream_t stream);
 
+/* Node tiles for the LDS-staged message kernel (north_star: "LDS staging of node tiles for edge gather"; the gathers it
+ * replaces are PyG propagate's x_i = x[edge_index[1]], x_j = x[edge_index[0]], experiments/models_gnn.py:65,128).
+ * A tile = `tile_nodes` consecutive TARGET nodes with all their in-edges (at most MSMP_TILE_EDGES) plus every node those
+ * edges read as a source: at most MSMP_TILE_NCAP distinct nodes, listed per tile with the targets first (slot k < tile size
+ * is node tile * tile_nodes + k), so the kernel loads each node row of a tile ONCE (coalesced, 512-byte rows) into LDS and
+ * every edge reads its two operands from there through the per-edge slot pair.  Works for any graph whose tiles fit (banded
+ * 1-D radius / knn graphs, periodic wrap-around included: the list is by node id, not by window); msmp_build_tiles reports
+ * the largest list / edge count it met so the caller can pick a smaller tile_nodes or fall back to the gather kernels. */
+#define MSMP_TILE_NCAP  32       /* distinct nodes of a tile: one 32-row MFMA block */
+#define MSMP_TILE_EDGES 128      /* in-edges of a tile: one 32-edge block per wave */
+typedef struct {
+    int32_t tile_nodes;          /* target nodes per tile */
+    int32_t n_tiles;             /* ceil(n_nodes / tile_nodes) */
+    const int32_t* tile_node;    /* [n_tiles][MSMP_TILE_NCAP] node ids (unused slots repeat the tile's first node) */
+    const int32_t* tile_count;   /* [n_tiles] number of valid slots */
+    const int32_t* edge_slot;    /* [E] per CSR edge: target slot | source slot << 8 */
+} msmp_tiles_t;
+/* stats_out (device, 2 x int32): largest node list, largest edge count over the tiles (lists longer than MSMP_TILE_NCAP are
+ * truncated in the output: the structure is then not usable with this tile_nodes). */
+int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int64_t n_edges, int tile_nodes,
+                     int32_t* tile_node_out, int32_t* tile_count_out, int32_t* edge_slot_out, int32_t* stats_out,
+                     msmp_stream_t stream);
+/* L1 + L2 on node tiles: same result as msmp_edge_aggregate_projected_f32 (p, q given: the tile's P / Q rows are staged in
+ * LDS) or, with p == q == NULL, as msmp_node_project_f32 + msmp_edge_aggregate_projected_f32 in ONE launch: the tile's h / u /
+ * pos / vars rows are staged in LDS, P and Q of the tile's nodes are computed there (halo nodes recomputed per tile) and never
+ * touch HBM. */
+int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, const float* pos, const float* vars, const float* p,
+                                  const float* q, const int32_t* rowptr, const msmp_tiles_t* tiles, int64_t n_nodes,
+                                  int64_t n_edges, int tw, int nv, const float* packed, float* agg_out, msmp_stream_t stream);
+
 /* L2  PyG aggr='mean' (torch_scatter scatter-mean; experiments/models_gnn.py:42,107):
  *   agg[i] = sum_{e in CSR row i} msg[e] / max(deg_i, 1), fixed summation order (CSR order). */
 int msmp_scatter_mean_f32(const float* msg, const int32_t* rowptr, int64_t n_nodes,
@@ -191,10 +223,12 @@ int msmp_gate_blend_f32(const float* h, const float* gate_pre, const float* main
  * gated pair of one iteration of the solver loop (L5) is evaluated and blended.  h_out may not alias h.
  * max_in_degree = largest CSR row length (pass -1 if unknown): when <= 256 the fused L1+L2 kernel is
  * used, otherwise the message tensor goes through the workspace; max_graph_nodes as in
- * msmp_instance_norm_f32.  Workspace size from msmp_mp_layer_workspace_bytes (same max_in_degree). */
+ * msmp_instance_norm_f32.  Workspace size from msmp_mp_layer_workspace_bytes (same max_in_degree).
+ * tiles (may be NULL): node tiles of the structure (msmp_build_tiles); with them rows L1 + L2 run on the LDS-staged tile
+ * kernel (msmp_edge_aggregate_tiled_f32, per-node projections folded in), without them on the gather kernels. */
 size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges, int gated, int max_in_degree);
 int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars,
-                      const int32_t* rowptr, const int32_t* col, const int32_t* tgt,
+                      const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const msmp_tiles_t* tiles,
                       const int32_t* graph_ptr, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
                       int max_in_degree, int max_graph_nodes, int tw, int nv, const float* packed_main,
                       const float* packed_gate, int mode,

@@ -7,6 +7,14 @@ from ctypes import c_int, c_int64, c_size_t, c_void_p, c_float, c_double, c_char
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MSMP_LIB_PATH') or os.path.join(PKG, 'libmsmp_pde.so')     # MSMP_LIB_PATH: a diagnostic build of the same library
 
+class MsmpTiles(ctypes.Structure):
+    """msmp_tiles_t (include/msmp_pde.h): node tiles of the LDS-staged message kernel."""
+    _fields_ = [('tile_nodes', ctypes.c_int32), ('n_tiles', ctypes.c_int32), ('tile_node', c_void_p), ('tile_count', c_void_p),
+                ('edge_slot', c_void_p)]
+
+
+MSMP_TILE_NCAP = 32
+MSMP_TILE_EDGES = 128
 MSMP_LAYER_RESIDUAL_SWISH = 0
 MSMP_LAYER_LIN = 1
 MSMP_ERR_UNSUPPORTED = -2
@@ -34,8 +42,10 @@ SIGNATURES = {
     'msmp_edge_aggregate_f32': (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'msmp_node_project_f32': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'msmp_edge_aggregate_projected_f32': (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'msmp_build_tiles': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'msmp_edge_aggregate_tiled_f32': (c_int, [c_void_p] * 7 + [ctypes.POINTER(MsmpTiles), c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'msmp_mp_layer_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int, c_int]),
-    'msmp_mp_layer_f32': (c_int, [c_void_p] * 8 + [c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+    'msmp_mp_layer_f32': (c_int, [c_void_p] * 7 + [ctypes.POINTER(MsmpTiles), c_void_p] + [c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                                    c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     'msmp_packed_lem_floats': (c_int64, []),
     'msmp_pack_lem_f32': (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p]),

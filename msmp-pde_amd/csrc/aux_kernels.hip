@@ -457,7 +457,8 @@ extern "C" size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges
 }
 
 extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars,
-                                 const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const int32_t* graph_ptr,
+                                 const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const msmp_tiles_t* tiles,
+                                 const int32_t* graph_ptr,
                                  int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int max_in_degree, int max_graph_nodes,
                                  int tw, int nv, const float* packed_main, const float* packed_gate, int mode, float eps, float* h_out,
                                  void* workspace, size_t workspace_bytes, msmp_stream_t stream) {
@@ -482,7 +483,15 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
     float* qbuf = (float*)(ws + 4 * nod);
     int rc;
     // message + mean (rows L1 + L2): one fused launch when every target's in-edges fit a workgroup tile
+    const int tile_mode = (tiles && n_edges > 0 && msmp_tune_get("split")) ? msmp_tune_get("tile") : 0;
     auto aggregate = [&](const float* packed, float* agg) -> int {
+        if (fused && !dense && tile_mode == 2)       // node tiles staged in LDS, P / Q computed in the workgroup
+            return msmp_edge_aggregate_tiled_f32(h, u, pos, vars, nullptr, nullptr, rowptr, tiles, n_nodes, n_edges, tw, nv, packed, agg, stream);
+        if (fused && !dense && tile_mode == 1) {
+            const int r = msmp_node_project_f32(h, u, pos, vars, n_nodes, tw, nv, packed, pbuf, qbuf, stream);
+            return r ? r : msmp_edge_aggregate_tiled_f32(nullptr, nullptr, nullptr, nullptr, pbuf, qbuf, rowptr, tiles, n_nodes, n_edges, tw,
+                                                         nv, packed, agg, stream);
+        }
         if (fused && !dense) {
             const int r = msmp_node_project_f32(h, u, pos, vars, n_nodes, tw, nv, packed, pbuf, qbuf, stream);
             return r ? r : msmp_edge_aggregate_projected_f32(pbuf, qbuf, rowptr, col, tgt, n_nodes, n_edges, max_in_degree, tw,
@@ -497,7 +506,10 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
     // node tail (rows L3-L5): one launch per layer when the graphs fit a workgroup (update head(s) + InstanceNorm + blend)
     if (msmp_tune_get("split") && msmp_tune_get("tail") && max_graph_nodes > 0 && max_graph_nodes <= 128) {
         rc = MSMP_ERR_UNSUPPORTED;
-        if (gated && fused && !dense)       // small batches: both heads per launch (projection, then message + mean)
+        if (gated && fused && !dense && tile_mode == 2 && msmp_tune_get("pair") && (msmp_tune_get("pair") == 2 || n_nodes <= 65536))
+            rc = msmp_edge_aggregate_tiled_pair(h, u, pos, vars, rowptr, tiles, n_nodes, n_edges, tw, nv, packed_gate, packed_main, pre_gate,
+                                                agg, stream);      // small batches: both heads in one launch
+        else if (gated && fused && !dense && !tile_mode)       // small batches: both heads per launch (projection, then message + mean)
             rc = msmp_pair_project_aggregate(h, u, pos, vars, rowptr, col, tgt, n_nodes, n_edges, max_in_degree, tw, nv, packed_gate,
                                              packed_main, pbuf, qbuf, pre_main, (float*)(ws + 5 * nod), pre_gate, agg, stream);
         if (rc == MSMP_ERR_UNSUPPORTED) {

@@ -993,6 +993,7 @@ struct TailArgs {
 struct HeadRows {
     f32x4 pf[4][4];
 };
+constexpr float TAIL_ACT_SCALE = 64.0f;
 __device__ __forceinline__ void head_row_load(const float* __restrict__ h, const float* __restrict__ agg, long nc, int hh, int ch,
                                               f32x4 (&dst)[4]) {
     const float* row32 = (ch < 4 ? h : agg) + (size_t)nc * H + 32 * (ch & 3);
@@ -1012,7 +1013,9 @@ __device__ __forceinline__ void head_compute(HeadRows& st, const float* __restri
                                              const float* __restrict__ vars, long nc, int nv, const float* b3, const float* b4,
                                              const float* w3vh, const float* w3s, const float* w4t, const float* scales, float* lds,
                                              int tid, int lane, int c, int hh, f32x16 (&yT)[4], MidHook mid_hook PROF_ARGS) {
-    const float sc3 = scales[2], inv3 = scales[6], sc4 = scales[3];
+    // ACT_SCALE: the node rows and the Swish output enter the split GEMMs multiplied by 2^6, so that the fp16 low halves of small
+    // activations stay normal (see tile_kernels.hip); every factor is a power of two folded into an existing constant.
+    const float sc3 = scales[2] * TAIL_ACT_SCALE, inv3 = scales[6], sc4 = scales[3] * TAIL_ACT_SCALE;
     WStage ws;
     wstage_load(ws, w3s, tid);
     float xv[8];
@@ -1028,14 +1031,14 @@ __device__ __forceinline__ void head_compute(HeadRows& st, const float* __restri
         half8 bhi[1][2], blo[1][2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const f32x4 v0 = st.pf[ch & 3][2 * s], v1 = st.pf[ch & 3][2 * s + 1];
+            const f32x4 v0 = st.pf[ch & 3][2 * s] * TAIL_ACT_SCALE, v1 = st.pf[ch & 3][2 * s + 1] * TAIL_ACT_SCALE;
             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             split8(v, bhi[0][s], blo[0][s]);
         }
         if (ch + 4 < 8) head_row_load(h, agg, nc, hh, ch + 4, st.pf[ch & 3]);
         if (ch == 5) {      // the variables and their slot fragments are consumed after the k loop: issued two chunks ahead
 #pragma unroll
-            for (int f = 0; f < 8; ++f) xv[f] = f < nv ? vars[(size_t)nc * nv + f] : 0.f;
+            for (int f = 0; f < 8; ++f) xv[f] = f < nv ? vars[(size_t)nc * nv + f] * TAIL_ACT_SCALE : 0.f;
             const half8* wv = reinterpret_cast<const half8*>(w3vh) + lane;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -1063,7 +1066,15 @@ __device__ __forceinline__ void head_compute(HeadRows& st, const float* __restri
 #pragma unroll
     for (int T = 0; T < 4; ++T)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z[T][0][r] = swishf(z[T][0][r] * inv3);
+        for (int r = 0; r < 16; ++r) {         // z' = ACT_SCALE Swish(x), x = acc 2^-s3 / ACT_SCALE: same instruction count as Swish(x)
+#if MSMP_PRECISE_ACT
+            z[T][0][r] = TAIL_ACT_SCALE * swishf(z[T][0][r] * inv3 * (1.0f / TAIL_ACT_SCALE));
+#else
+            const float xs = z[T][0][r] * inv3;
+            const float e = __builtin_amdgcn_exp2f(xs * (-1.44269504088896340736f / TAIL_ACT_SCALE));
+            z[T][0][r] = xs * __builtin_amdgcn_rcpf(1.0f + e);
+#endif
+        }
 
     {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(b4 + 4 * c) * sc4;
@@ -1179,7 +1190,7 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
         head_compute(rows, a.h, a.agg[1], a.vars, nc, a.nv, a.b3[1], a.b4[1], a.w3vh[1], a.w3s[1], a.w4t[1], a.scales[1], lds, tid, lane,
                      c, hh, tau, [&] { head_rows_issue(a.h, a.agg[0], nc, hh, rows); } PROF_PASS);
         PROF_MARK(0);
-        tile_t_instance_norm(tau, wave, cnt, a.scales[1][7], a.eps, part, tot, tid, c, hh);
+        tile_t_instance_norm(tau, wave, cnt, a.scales[1][7] * (1.0f / TAIL_ACT_SCALE), a.eps, part, tot, tid, c, hh);
 #pragma unroll
         for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -1212,7 +1223,7 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
             }
         }
     }
-    float unit = a.scales[0][7];
+    float unit = a.scales[0][7] * (1.0f / TAIL_ACT_SCALE);
     if (!GATED && a.mode != MSMP_LAYER_LIN) {
 #pragma unroll
         for (int T = 0; T < 4; ++T)
@@ -1298,17 +1309,20 @@ static int g_edge_ws = 0;    // 1: persistent weight-stationary message + mean k
                              // measured equal to the streamed-weight kernel (2.43 vs 2.41 ms per step), so the latter stays the default
 static int g_pair = 1;       // gated pair: both heads' projection / message kernels in one launch each: 0 never, 1 up to PAIR_MAX_NODES nodes, 2 always
 constexpr int64_t PAIR_MAX_NODES = 65536;     // measured (E2, ms per rollout step, per-head vs paired): 256 graphs 1.33 / 1.14, 512: 2.06 / 1.95, 1024: 3.63 / 3.65, 2048: 6.95 / 7.07
+static int g_tile = 2;       // node tiles (tile_kernels.hip): 2 fold the projections into the message kernel, 1 staged P / Q rows, 0 off
 static int g_tail = 1;       // fused node tail (msmp_node_tail_f32) inside msmp_mp_layer_f32; msmp_tune("tail", 0) chains the pieces
 int msmp_tune_get(const char* key) {
     if (!strcmp(key, "split")) return g_split;
     if (!strcmp(key, "tail")) return g_tail;
     if (!strcmp(key, "pair")) return g_pair;
+    if (!strcmp(key, "tile")) return g_tile;
     return 0;
 }
 
 extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "tail")) { g_tail = value; return MSMP_OK; }
     if (key && !strcmp(key, "pair")) { g_pair = value; return MSMP_OK; }
+    if (key && !strcmp(key, "tile")) { g_tile = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_ws")) { g_edge_ws = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_xcd")) { g_edge_xcd = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_ws_waves")) { g_edge_ws_waves = value; return MSMP_OK; }

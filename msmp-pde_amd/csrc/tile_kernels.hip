@@ -1,0 +1,587 @@
+// LDS-staged node tiles for the message kernel (rows L1 + L2; north_star "LDS staging of node tiles for edge gather").
+//
+// The reference gathers x_i = x[edge_index[1]], x_j = x[edge_index[0]] per EDGE (PyG propagate, experiments/models_gnn.py:65,128).
+// Here a workgroup owns a tile of `tile_nodes` consecutive target nodes with all their in-edges (<= 128) and the <= 32 distinct
+// nodes those edges touch (msmp_tiles_t, built once per graph structure by msmp_build_tiles).  Each node row of the tile is
+// loaded ONCE, coalesced, and every edge then reads its two operands from LDS:
+//   FOLD = false: the tile's P / Q rows (msmp_node_project_f32) are staged, [slot][128] fp32, row stride 132 floats
+//                 (conflict-free ds_read_b128: a 16-lane group reads one 16-byte piece of 16 different or equal rows);
+//   FOLD = true : the tile's h rows and [u, pos, vars] columns are staged as fp16 hi/lo fragments, P and Q of the tile's
+//                 nodes are computed in the workgroup (one 32-node MFMA block; wave w owns output channels 32w..32w+31 of
+//                 both, its weight fragments come straight from the L2-resident packed blob) and written to the same LDS
+//                 rows: message_net_1's per-node projections never touch HBM, halo nodes are recomputed per tile.
+// After that the kernel is the factorised message kernel of mlp_kernels.hip: Swish(P_i + Q_j) formed in the B-operand registers
+// of message_net_2 (fp16-split MFMA, weights streamed through LDS), Swish, per-target mean in CSR order through LDS.
+#include "mfma_tiles.h"
+
+namespace msmp {
+
+// Phase profile (build with MSMP_PROF=tile in the environment of build.py; scripts/prof_tile.py reads it): cycle sums of wave 0 of
+// every workgroup per phase, kept in registers and added to g_prof_tile once at the end.
+#if MSMP_PROF_TILE
+__device__ unsigned long long g_prof_tile[16];
+#define TPROF_DECL long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tp = __builtin_readcyclecounter();
+#define TPROF(i) do { const long long t_ = __builtin_readcyclecounter(); pacc[i] += t_ - tp; tp = t_; } while (0)
+#define TPROF_FLUSH if (tid == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_prof_tile[i_], (unsigned long long)pacc[i_]);
+#else
+#define TPROF_DECL
+#define TPROF(i)
+#define TPROF_FLUSH
+#endif
+
+constexpr int TILE_NCAP = MSMP_TILE_NCAP;
+constexpr int TILE_EDGES = MSMP_TILE_EDGES;
+constexpr int PQLD = H + 4;                       // LDS row stride of a staged P / Q row (floats): 33 x 16 B
+constexpr int BROW_T = 72;                        // halfs per staged fragment row: [hi 32 | lo 32] + 16 B pad (as node_proj's B tile)
+constexpr int WBUF_FLOATS = 2 * H * LDW;          // weight double buffer / epilogue staging / (FOLD) fragment tile: 36 864 B
+constexpr int TILE_LDS_FLOATS = WBUF_FLOATS + 2 * TILE_NCAP * PQLD;
+// Activations enter the fp16-split GEMMs multiplied by 2^6.  The low half of a value x is fp16(x - fp16(x)) ~ 2^-11 x: for
+// |x| < 0.25 it falls into the fp16 subnormals (quantum 6e-8), i.e. the split then carries x with an ABSOLUTE error of 3e-8
+// instead of a relative 2^-23.  Hidden states right behind the encoder and the pre-activations of the first layers are that
+// small, and the InstanceNorm that follows divides by their (equally small) per-graph spread (measured: layer pair 0 of E2, 2.4x
+// the error of a float32 evaluation; scripts/diag_layer.py).  With 2^6 every |x| > 4e-3 keeps a normal low half; all factors
+// are powers of two folded into constants that were there anyway (no extra instruction); the fp16 range then covers |x| < 1023 (2^8 was measured too: 3.2x instead of 3.6x the float32 floor on the worst case, not worth the lost range).
+constexpr float ACT_SCALE = 64.0f;
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Tile metadata: one 128-thread workgroup per tile.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int n_nodes,
+                                                          int tile_nodes, int* __restrict__ tile_node, int* __restrict__ tile_count,
+                                                          int* __restrict__ edge_slot, int* __restrict__ stats) {
+    __shared__ int s_col[TILE_EDGES];
+    __shared__ int s_first[TILE_EDGES];     // 1: first occurrence of an out-of-range source
+    __shared__ int s_slot[TILE_EDGES];
+    const int t = blockIdx.x, k = threadIdx.x;
+    const int n0 = t * tile_nodes, n1 = min(n0 + tile_nodes, n_nodes);
+    const int e0 = rowptr[n0], e1 = rowptr[n1];
+    const int ne = e1 - e0, nt = n1 - n0;
+    const int nek = min(ne, TILE_EDGES);
+    int j = -1;
+    if (k < nek) j = col[e0 + k];
+    s_col[k] = j;
+    __syncthreads();
+    int first = 0, owner = k;
+    if (k < nek && (j < n0 || j >= n1)) {
+        first = 1;
+        for (int i = 0; i < k; ++i)
+            if (s_col[i] == j) { first = 0; owner = i; break; }
+    }
+    s_first[k] = first;
+    __syncthreads();
+    int slot = 0;
+    if (k < nek) {
+        if (j >= n0 && j < n1) slot = j - n0;
+        else if (first) {
+            int before = 0;
+            for (int i = 0; i < k; ++i) before += s_first[i];
+            slot = nt + before;
+        }
+    }
+    s_slot[k] = slot;
+    __syncthreads();
+    if (k < nek && !(j >= n0 && j < n1) && !first) slot = s_slot[owner];
+    // outputs
+    if (k < nek) {
+        // target slot of edge e0 + k: the CSR row it lies in (rows of a tile are short: linear search over <= tile_nodes rows)
+        int ts = 0;
+        while (ts + 1 < nt && rowptr[n0 + ts + 1] <= e0 + k) ++ts;
+        edge_slot[e0 + k] = ts | (min(slot, 255) << 8);
+        if (first && slot < TILE_NCAP) tile_node[(size_t)t * TILE_NCAP + slot] = j;
+    }
+    if (k < TILE_NCAP && k < nt) tile_node[(size_t)t * TILE_NCAP + k] = n0 + k;
+    __syncthreads();
+    if (k == 0) {
+        int total = nt;
+        for (int i = 0; i < nek; ++i) total += s_first[i];
+        tile_count[t] = min(total, TILE_NCAP);
+        atomicMax(&stats[0], total);
+        atomicMax(&stats[1], ne);
+    }
+    // unused slots repeat the first node (valid addresses for unconditional loads): slots >= total were never written above
+    __syncthreads();
+    if (k < TILE_NCAP) {
+        int total = nt;
+        for (int i = 0; i < nek; ++i) total += s_first[i];
+        if (k >= total) tile_node[(size_t)t * TILE_NCAP + k] = n0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+struct TileArgs {
+    const float* h;        // FOLD
+    const float* u;
+    const float* pos;
+    const float* vars;
+    const float* P;        // !FOLD
+    const float* Q;
+    const int* rowptr;
+    const int* tile_node;
+    const int* tile_count;
+    const int* edge_slot;
+    long n_nodes, n_edges;
+    int tile_nodes;
+    int tw, nv, nc1;
+    const float* w1s;      // FOLD: nc1 split chunks, natural k order, fragment row (T, lane) = W1 row 32 T + lane
+    const float* w2s;      // 4 split chunks (acc order)
+    const float* scales;   // [8]
+    const float* b1;
+    const float* b2;
+    float* agg;
+};
+
+template <bool FOLD>
+__device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
+    float* wbuf = lds;                               // W2 chunks (2 x 16 KB) / epilogue staging / (FOLD) fragment tile
+    float* pl = lds + WBUF_FLOATS;                   // P rows [32][PQLD]
+    float* ql = pl + TILE_NCAP * PQLD;               // Q rows [32][PQLD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const int tile = blockIdx.x;
+    const int tile_n0 = tile * a.tile_nodes;
+    const int tile_n1 = (int)min((long)tile_n0 + a.tile_nodes, a.n_nodes);
+    const int tile_e0 = a.rowptr[tile_n0], tile_e1 = a.rowptr[tile_n1];
+    const int* tnode = a.tile_node + (size_t)tile * TILE_NCAP;
+
+    // this lane's edge and its two LDS rows
+    const int e = tile_e0 + wave * 32 + c;
+    const int ec = e < tile_e1 ? e : (tile_e1 > tile_e0 ? tile_e1 - 1 : 0);
+    int sl = a.edge_slot[ec];
+    if (tile_e1 == tile_e0) sl = 0;
+    const float* prow = pl + (sl & 255) * PQLD + 4 * hh;
+    const float* qrow = ql + ((sl >> 8) & 255) * PQLD + 4 * hh;
+
+    TPROF_DECL
+    WStage ws;
+    wstage_load(ws, a.w2s, tid);                     // W2 chunk 0, stored once the staging region is free
+
+    if (!FOLD) {
+        // stage the tile's P / Q rows: thread (row group tid >> 5, 16-byte piece tid & 31); a row = 32 consecutive lanes = 512 B
+        const int piece = tid & 31;
+        f32x4 pv[4], qv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int slot = (tid >> 5) + 8 * i;
+            const int node = tnode[slot];
+            pv[i] = *reinterpret_cast<const f32x4*>(a.P + (size_t)node * H + 4 * piece) * ACT_SCALE;
+            qv[i] = *reinterpret_cast<const f32x4*>(a.Q + (size_t)node * H + 4 * piece) * ACT_SCALE;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int slot = (tid >> 5) + 8 * i;
+            *reinterpret_cast<f32x4*>(pl + slot * PQLD + 4 * piece) = pv[i];
+            *reinterpret_cast<f32x4*>(ql + slot * PQLD + 4 * piece) = qv[i];
+        }
+        wstage_store_linear(ws, wbuf, tid);
+        __syncthreads();
+        TPROF(0);
+    } else {
+        // ---- stage the tile's node rows as fp16 hi/lo fragments (natural k order) ------------------------------------
+        //   chunk ch = 0..3: h columns 32 ch .. 32 ch + 31;  chunk 4 + 2 j / 5 + 2 j: tail columns 32 j .. (P / Q variant)
+        //   row layout [node 32][hi 32 halfs | lo 32 halfs | pad] (BROW_T halfs), chunk stride 32 * BROW_T
+        _Float16* bt = reinterpret_cast<_Float16*>(wbuf);
+        using half4 = __attribute__((ext_vector_type(4))) _Float16;
+        const int ntail = a.nc1 - 8;
+        {
+            f32x4 hv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i;               // node = idx >> 5, 16-byte piece idx & 31
+                const int node = tnode[idx >> 5];
+                hv[i] = *reinterpret_cast<const f32x4*>(a.h + (size_t)node * H + 4 * (idx & 31));
+            }
+            // tail features of (node = tid >> 3, columns 4 g .. 4 g + 3 of every tail chunk), g = tid & 7
+            const int tn = tnode[tid >> 3];
+            const int g = tid & 7;
+            float tx[2][4];
+#pragma unroll
+            for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int k = 32 * jc + 4 * g + m;
+                    const float uv = a.u[(size_t)tn * a.tw + min(k, a.tw - 1)];
+                    const float vv = a.vars[(size_t)tn * a.nv + min(max(k - a.tw - 1, 0), a.nv - 1)];
+                    tx[jc][m] = k < a.tw ? uv : (k == a.tw ? a.pos[tn] : (k <= a.tw + a.nv ? vv : 0.f));
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i;
+                half4 hi, lo;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float xs = hv[i][m] * ACT_SCALE;
+                    const _Float16 x = (_Float16)xs;
+                    hi[m] = x;
+                    lo[m] = (_Float16)(xs - (float)x);
+                }
+                const int piece = idx & 31;
+                _Float16* row = bt + ((piece >> 3) * 32 + (idx >> 5)) * BROW_T + 4 * (piece & 7);
+                *reinterpret_cast<half4*>(row) = hi;
+                *reinterpret_cast<half4*>(row + 32) = lo;
+            }
+#pragma unroll
+            for (int jc = 0; jc < 2; ++jc) {
+                if (jc < ntail) {
+                    half4 phi, plo, qhi, qlo;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int k = 32 * jc + 4 * g + m;
+                        const float xp = tx[jc][m] * ACT_SCALE;
+                        const float xq = k <= a.tw ? -xp : 0.f;
+                        const _Float16 ph = (_Float16)xp, qh = (_Float16)xq;
+                        phi[m] = ph;
+                        plo[m] = (_Float16)(xp - (float)ph);
+                        qhi[m] = qh;
+                        qlo[m] = (_Float16)(xq - (float)qh);
+                    }
+                    _Float16* rp = bt + ((4 + 2 * jc) * 32 + (tid >> 3)) * BROW_T + 4 * g;
+                    _Float16* rq = bt + ((5 + 2 * jc) * 32 + (tid >> 3)) * BROW_T + 4 * g;
+                    *reinterpret_cast<half4*>(rp) = phi;
+                    *reinterpret_cast<half4*>(rp + 32) = plo;
+                    *reinterpret_cast<half4*>(rq) = qhi;
+                    *reinterpret_cast<half4*>(rq + 32) = qlo;
+                }
+            }
+        }
+        __syncthreads();
+        TPROF(0);
+
+        // ---- P, Q of the tile's 32 node slots, transposed: A = node fragments (LDS), B = this wave's weight fragments ----
+        // accP / accQ [node acc_row(r, hh)][channel 32 wave + c]; weights carry 2^s (scales[0]), the node fragments ACT_SCALE; the
+        // rows written to LDS are ACT_SCALE * P, ACT_SCALE * Q (what the activation below wants), so only 2^-s is taken out.
+        const float sc = a.scales[0] * ACT_SCALE, inv = a.scales[4];
+        f32x16 accP, accQ;
+        {
+            const float bv = a.b1[32 * wave + c] * sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accP[r] = bv; accQ[r] = 0.f; }
+        }
+        // fragment (s, plane) of chunk `ch`, row tile `wave`: lane-linear 16 bytes
+        auto wfrag = [&](int ch, int s, int plane) {
+            return reinterpret_cast<const half8*>(a.w1s + (size_t)ch * SPLIT_CHUNK_FLOATS)[((s * 4 + wave) * 2 + plane) * 64 + lane];
+        };
+        auto afrag = [&](int ch, half8 (&ahi)[2], half8 (&alo)[2]) {
+            const _Float16* row = bt + (ch * 32 + c) * BROW_T + 8 * hh;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                ahi[s] = *reinterpret_cast<const half8*>(row + 16 * s);
+                alo[s] = *reinterpret_cast<const half8*>(row + 32 + 16 * s);
+            }
+        };
+        auto mma3 = [&](f32x16& acc, const half8& ahi, const half8& alo, const half8& whi, const half8& wlo) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wlo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, whi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi, acc, 0, 0, 0);
+        };
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            half8 wp[2][2], wq[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) { wp[s][p] = wfrag(ch, s, p); wq[s][p] = wfrag(4 + ch, s, p); }
+            half8 ahi[2], alo[2];
+            afrag(ch, ahi, alo);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                mma3(accP, ahi[s], alo[s], wp[s][0], wp[s][1]);
+                mma3(accQ, ahi[s], alo[s], wq[s][0], wq[s][1]);
+            }
+        }
+        for (int jc = 0; jc < ntail; ++jc) {
+            half8 wt[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) wt[s][p] = wfrag(8 + jc, s, p);
+            half8 phi[2], plo[2], qhi[2], qlo[2];
+            afrag(4 + 2 * jc, phi, plo);
+            afrag(5 + 2 * jc, qhi, qlo);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                mma3(accP, phi[s], plo[s], wt[s][0], wt[s][1]);
+                mma3(accQ, qhi[s], qlo[s], wt[s][0], wt[s][1]);
+            }
+        }
+        TPROF(1);
+        // rows of this lane: slot acc_row(r, hh), channel 32 wave + c
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int slot = acc_row(r, hh);
+            pl[slot * PQLD + 32 * wave + c] = accP[r] * inv;
+            ql[slot * PQLD + 32 * wave + c] = accQ[r] * inv;
+        }
+        __syncthreads();                             // P / Q visible; every wave is done with the fragment tile
+        wstage_store_linear(ws, wbuf, tid);
+        __syncthreads();
+        TPROF(2);
+    }
+
+    // ---- message_net_2 on Swish(P_i + Q_j) ---------------------------------------------------------------------------------
+    // Software pipeline, one barrier region per 32-channel K chunk t: the matrix work of chunk t (24 MFMAs = 8 groups of 3 on
+    // one accumulator each) is interleaved IN PROGRAM ORDER with the activation work of chunk t + 1 (8 slices of two values:
+    // P + Q from LDS, Swish, fp16 hi/lo split), pinned with scheduling barriers: a wave's MFMAs issue back to back while its own
+    // vector instructions fill the issue slots in between (an MFMA blocks vector issue for 8 of its 32 cycles), instead of
+    // the two phases alternating.  The A fragments of a chunk (16 x 16 B per lane) are all requested up front.
+    // The LDS rows hold ACT_SCALE (P, Q), so z' = ACT_SCALE Swish(x) = x' / (1 + 2^(c x' / ACT_SCALE)) costs what Swish(x) did.
+    f32x16 y[4];
+    {
+        const float s2 = a.scales[1] * ACT_SCALE;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b2 + 32 * T + 8 * q + 4 * hh);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) y[T][4 * q + m] = bv[m] * s2;
+            }
+    }
+    f32x4 pq[8];                 // P (0..3) and Q (4..7) pieces of the chunk being activated: channels 32 t + 8 q + 4 hh .. + 3
+    auto gather_tile = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pq[q] = *reinterpret_cast<const f32x4*>(prow + 32 * t + 8 * q);
+            pq[4 + q] = *reinterpret_cast<const f32x4*>(qrow + 32 * t + 8 * q);
+        }
+    };
+    // activation of two values (slice i = 0..7 of a chunk: piece q = i >> 1, elements 2 (i & 1), +1) into zt; written on float
+    // pairs so that the sums and products become packed instructions (v_pk_add_f32 / v_pk_mul_f32: two values per issue slot)
+    float zt[16];
+    auto act_slice = [&](int i) {
+        const int q = i >> 1, m0 = 2 * (i & 1);
+#if MSMP_PRECISE_ACT
+        for (int m = m0; m < m0 + 2; ++m) zt[4 * q + m] = ACT_SCALE * swishf((pq[q][m] + pq[4 + q][m]) * (1.0f / ACT_SCALE));
+#else
+        const f32x2 x = f32x2{pq[q][m0], pq[q][m0 + 1]} + f32x2{pq[4 + q][m0], pq[4 + q][m0 + 1]};
+        const f32x2 t = x * f32x2{-1.44269504088896340736f / ACT_SCALE, -1.44269504088896340736f / ACT_SCALE};
+        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+        const f32x2 z = x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        zt[4 * q + m0] = z[0];
+        zt[4 * q + m0 + 1] = z[1];
+#endif
+    };
+    half8 bhi[2][2], blo[2][2];      // [parity of the chunk][K = 16 step]: B fragments (acc order: registers 8 s .. 8 s + 7)
+    auto split_step = [&](int par, int s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = zt[8 * s + j];
+        split8(v, bhi[par][s], blo[par][s]);
+    };
+    gather_tile(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) act_slice(i);
+    split_step(0, 0);
+    split_step(0, 1);
+    gather_tile(1);
+    TPROF(3);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int par = t & 1;
+        if (t < 3) wstage_load(ws, a.w2s + (size_t)(t + 1) * SPLIT_CHUNK_FLOATS, tid);
+        const half8* w = reinterpret_cast<const half8*>(wbuf + par * SPLIT_CHUNK_FLOATS) + lane;
+        half8 ahi[2][4], alo[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                ahi[s][T] = w[((s * 4 + T) * 2 + 0) * 64];
+                alo[s][T] = w[((s * 4 + T) * 2 + 1) * 64];
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int s = g >> 2, T = g & 3;
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[s][T], bhi[par][s], y[T], 0, 0, 0);
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s][T], blo[par][s], y[T], 0, 0, 0);
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s][T], bhi[par][s], y[T], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t < 3) {
+                act_slice(g);
+                if (g == 3) split_step(par ^ 1, 0);
+                if (g == 7) split_step(par ^ 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (t < 2) gather_tile(t + 2);          // P / Q pieces of the chunk after next: consumed in the next region
+        TPROF(4);
+        if (t < 3) {
+            wstage_store_linear(ws, wbuf + (par ^ 1) * SPLIT_CHUNK_FLOATS, tid);
+            __syncthreads();
+        }
+        TPROF(5);
+    }
+
+    // ---- mean over the in-edges of each target (same order of additions as scatter_mean_kernel: CSR order) -----------------
+    // Swish(y 2^-s2) = 2^-s2 y / (1 + 2^(c y)), c = -log2(e) 2^-s2: the power of two is applied once per node with the 1 / deg
+    // factor (exact, so the result is bit-identical to scaling every message first).
+    // One round: the staged messages [128 edges][128 channels] (row stride 132 floats) take the whole LDS (the W2 buffers and
+    // the P / Q rows are dead by now: 67.6 of the 70.6 KB).  Thread (node slot tid >> 5, channel group tid & 31) then sums the
+    // rows of nodes slot, slot + 8, ... in CSR order: up to 8 rows per node are read unconditionally (index clamped into the
+    // node's own rows) and accumulated with a 0 / 1 factor (fma(v, 1, s) = s + v and fma(v, 0, s) = s exactly, so the sum equals
+    // the sequential one bit for bit); longer rows loop.
+    constexpr int LDR = H + 4;
+    static_assert(TILE_EDGES * LDR <= TILE_LDS_FLOATS, "staged messages must fit the kernel's LDS");
+    const float inv2 = a.scales[5] * (1.0f / ACT_SCALE);        // the accumulators carry 2^s2 ACT_SCALE
+#if MSMP_PRECISE_ACT
+    const float post = 1.0f;
+#else
+    const float cexp = -1.44269504088896340736f * inv2;
+    const float post = inv2;
+#endif
+    // row bounds of this thread's nodes (prefetched: global loads in flight during the activation below)
+    const int nslot = tid >> 5, cq = tid & 31;
+    int r0b[4], r1b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int node = tile_n0 + nslot + 8 * k;
+        const int nodec = node < tile_n1 ? node : tile_n1 - 1;
+        const int v0 = a.rowptr[nodec], v1 = a.rowptr[nodec + 1];
+        r0b[k] = v0 - tile_e0;
+        r1b[k] = node < tile_n1 ? v1 - tile_e0 : v0 - tile_e0;
+    }
+    __syncthreads();     // readers of wbuf (W2 chunk 3) and of the P / Q rows are done
+    TPROF(6);
+    {
+        float* o = lds + (wave * 32 + c) * LDR + 4 * hh;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#if MSMP_PRECISE_ACT
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v[m] = swishf(y[T][4 * q + m] * inv2);
+#else
+#pragma unroll
+                for (int m = 0; m < 4; m += 2) {
+                    const f32x2 yy = {y[T][4 * q + m], y[T][4 * q + m + 1]};
+                    const f32x2 t = yy * f32x2{cexp, cexp};
+                    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+                    const f32x2 z = yy * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                    v[m] = z[0];
+                    v[m + 1] = z[1];
+                }
+#endif
+                *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = v;
+            }
+    }
+    TPROF(7);
+    __syncthreads();
+    TPROF(8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int node = tile_n0 + nslot + 8 * k;
+        if (node < tile_n1) {
+            const int r0 = r0b[k], r1 = r1b[k], deg = r1 - r0;
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+            if (deg > 0) {
+                for (int rb = r0; rb < r1; rb += 8) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(lds + min(rb + i, r1 - 1) * LDR + 4 * cq);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float m = rb + i < r1 ? 1.0f : 0.0f;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) sum[x] = __builtin_fmaf(v[i][x], m, sum[x]);
+                    }
+                }
+            }
+            const float invd = 1.0f / (float)max(deg, 1);
+            *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + 4 * cq) = (sum * post) * invd;
+        }
+    }
+    TPROF(9);
+    TPROF_FLUSH
+}
+
+template <bool FOLD>
+__global__ __launch_bounds__(256, 2) void edge_tile_kernel(TileArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[TILE_LDS_FLOATS];
+    edge_tile_body<FOLD>(a, lds);
+}
+
+// Both heads of a gated pair in ONE launch (blockIdx.y = head; same body, bit-identical results): small batches are bound by the
+// latency of their dependent launches, and with the projections folded in a gated pair is then two launches (this + the node tail).
+struct TileArgs2 {
+    TileArgs head[2];
+};
+__global__ __launch_bounds__(256, 2) void edge_tile_pair_kernel(TileArgs2 a) {
+    __shared__ __attribute__((aligned(16))) float lds[TILE_LDS_FLOATS];
+    edge_tile_body<true>(a.head[blockIdx.y], lds);
+}
+
+}  // namespace msmp
+
+using namespace msmp;
+
+#if MSMP_PROF_TILE
+extern "C" __attribute__((visibility("default"))) int msmp_debug_prof_tile(unsigned long long* out16, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_tile), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof_tile), 16 * sizeof(unsigned long long));
+}
+#endif
+
+extern "C" int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int64_t n_edges, int tile_nodes,
+                                int32_t* tile_node_out, int32_t* tile_count_out, int32_t* edge_slot_out, int32_t* stats_out,
+                                msmp_stream_t stream) {
+    MSMP_REQUIRE(rowptr && col && tile_node_out && tile_count_out && edge_slot_out && stats_out, MSMP_ERR_ARG, "msmp_build_tiles: null pointer");
+    MSMP_REQUIRE(n_nodes > 0 && n_edges >= 0 && n_nodes < (1L << 31) && n_edges < (1L << 31), MSMP_ERR_ARG, "msmp_build_tiles: bad sizes");
+    MSMP_REQUIRE(tile_nodes >= 1 && tile_nodes <= MSMP_TILE_NCAP, MSMP_ERR_ARG, "msmp_build_tiles: tile_nodes must be in 1..%d", MSMP_TILE_NCAP);
+    hipStream_t st = (hipStream_t)stream;
+    const hipError_t me = hipMemsetAsync(stats_out, 0, 2 * sizeof(int32_t), st);
+    MSMP_REQUIRE(me == hipSuccess, MSMP_ERR_HIP, "msmp_build_tiles: memset: %s", hipGetErrorString(me));
+    const unsigned n_tiles = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
+    hipLaunchKernelGGL(build_tiles_kernel, dim3(n_tiles), dim3(128), 0, st, rowptr, col, (int)n_nodes, tile_nodes, tile_node_out,
+                       tile_count_out, edge_slot_out, stats_out);
+    return check_launch("build_tiles_kernel");
+}
+
+extern "C" int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, const float* pos, const float* vars, const float* p,
+                                             const float* q, const int32_t* rowptr, const msmp_tiles_t* tiles, int64_t n_nodes,
+                                             int64_t n_edges, int tw, int nv, const float* packed, float* agg_out,
+                                             msmp_stream_t stream) {
+    MSMP_REQUIRE(rowptr && tiles && packed && agg_out, MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: null pointer");
+    MSMP_REQUIRE((p != nullptr) == (q != nullptr), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: give both of p, q or neither");
+    const bool fold = p == nullptr;
+    MSMP_REQUIRE(!fold || (h && u && pos && vars), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: null pointer (h, u, pos, vars)");
+    MSMP_REQUIRE(tiles->tile_node && tiles->tile_count && tiles->edge_slot && tiles->tile_nodes >= 1 && tiles->tile_nodes <= MSMP_TILE_NCAP,
+                 MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: bad tile descriptor");
+    MSMP_REQUIRE(n_nodes > 0 && n_edges >= 0 && n_nodes < (1L << 31) && n_edges < (1L << 31) && tw > 0 && nv >= 1 && nv <= MSMP_MAX_VARS,
+                 MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: bad sizes");
+    MSMP_REQUIRE((int64_t)tiles->n_tiles * tiles->tile_nodes >= n_nodes && (int64_t)(tiles->n_tiles - 1) * tiles->tile_nodes < n_nodes,
+                 MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: tile descriptor does not cover %ld nodes", (long)n_nodes);
+    MSMP_REQUIRE(msmp_tune_get("split"), MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_f32: only on the fp16-split matrix path");
+    const PackedLayout L = packed_layout(tw, nv);
+    MSMP_REQUIRE(!fold || L.nc1 - 8 <= 2, MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_f32: tw + 1 + nv <= 64");
+    TileArgs a{h, u, pos, vars, p, q, rowptr, tiles->tile_node, tiles->tile_count, tiles->edge_slot, (long)n_nodes, (long)n_edges,
+               tiles->tile_nodes, tw, nv, L.nc1, packed + L.w1s, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, agg_out};
+    hipStream_t st = (hipStream_t)stream;
+    timing_begin(MSMP_K_EDGE_MLP, st);
+    if (fold) hipLaunchKernelGGL(edge_tile_kernel<true>, dim3((unsigned)tiles->n_tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(edge_tile_kernel<false>, dim3((unsigned)tiles->n_tiles), dim3(256), 0, st, a);
+    timing_end(MSMP_K_EDGE_MLP, st);
+    return check_launch("edge_tile_kernel");
+}
+
+// Rows L1 + L2 of BOTH heads of a gated pair in one launch (library-internal; msmp_mp_layer_f32 at small batches).
+int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* pos, const float* vars, const int32_t* rowptr,
+                                   const msmp_tiles_t* tiles, int64_t n_nodes, int64_t n_edges, int tw, int nv, const float* packed_a,
+                                   const float* packed_b, float* agg_a, float* agg_b, msmp_stream_t stream) {
+    MSMP_REQUIRE(h && u && pos && vars && rowptr && tiles && packed_a && packed_b && agg_a && agg_b, MSMP_ERR_ARG,
+                 "msmp_edge_aggregate_tiled_pair: null pointer");
+    const PackedLayout L = packed_layout(tw, nv);
+    MSMP_REQUIRE(L.nc1 - 8 <= 2 && msmp_tune_get("split"), MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_pair: unsupported configuration");
+    TileArgs2 a2;
+    const float* packed[2] = {packed_a, packed_b};
+    float* agg[2] = {agg_a, agg_b};
+    for (int i = 0; i < 2; ++i)
+        a2.head[i] = TileArgs{h, u, pos, vars, nullptr, nullptr, rowptr, tiles->tile_node, tiles->tile_count, tiles->edge_slot, (long)n_nodes,
+                              (long)n_edges, tiles->tile_nodes, tw, nv, L.nc1, packed[i] + L.w1s, packed[i] + L.w2s, packed[i] + L.scales,
+                              packed[i] + L.b1, packed[i] + L.b2, agg[i]};
+    hipStream_t st = (hipStream_t)stream;
+    timing_begin(MSMP_K_EDGE_MLP, st);
+    hipLaunchKernelGGL(edge_tile_pair_kernel, dim3((unsigned)tiles->n_tiles, 2), dim3(256), 0, st, a2);
+    timing_end(MSMP_K_EDGE_MLP, st);
+    return check_launch("edge_tile_pair_kernel");
+}

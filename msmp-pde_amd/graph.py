@@ -68,6 +68,40 @@ class GraphStructure(object):
         self.max_in_degree = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if self.n_edges else 0
         self._key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
                      batch.data_ptr(), batch._version)
+        self._tiles = False        # not built yet (None = the structure does not fit node tiles)
+
+    def tiles(self):
+        """Node tiles of the LDS-staged message kernel (msmp_tiles_t; include/msmp_pde.h), built once per structure; None when
+        the graph does not tile (a tile of target nodes would touch more than MSMP_TILE_NCAP distinct nodes, or carry more than
+        MSMP_TILE_EDGES edges, unless it became too small to pay off): the callers then take the gather kernels.
+        tile_nodes: as many consecutive targets as fit 128 edges at the largest in-degree, then shrunk by the halo the first
+        attempt reported (banded graphs have a near-constant halo: a few retries, one device read-back each)."""
+        if self._tiles is not False:
+            return self._tiles
+        self._tiles = None
+        if self.n_edges == 0 or self.max_in_degree <= 0 or self.max_in_degree > _lib.MSMP_TILE_EDGES:
+            return None
+        L = lib()
+        dev = self.rowptr.device
+        tn0 = min(_lib.MSMP_TILE_NCAP, _lib.MSMP_TILE_EDGES // self.max_in_degree)
+        tn = tn0
+        for _attempt in range(4):
+            if tn < max(4, tn0 // 2):           # tiles this small waste the 128-edge block: not worth it
+                return None
+            n_tiles = (self.n_nodes + tn - 1) // tn
+            tile_node = torch.empty(n_tiles * _lib.MSMP_TILE_NCAP, dtype=torch.int32, device=dev)
+            tile_count = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+            edge_slot = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
+            stats = torch.empty(2, dtype=torch.int32, device=dev)
+            check(L.msmp_build_tiles(ptr(self.rowptr), ptr(self.col), self.n_nodes, self.n_edges, tn, ptr(tile_node), ptr(tile_count),
+                                     ptr(edge_slot), ptr(stats), current_stream()), 'msmp_build_tiles')
+            max_nodes, max_edges = (int(v) for v in stats.tolist())
+            if max_nodes <= _lib.MSMP_TILE_NCAP and max_edges <= _lib.MSMP_TILE_EDGES:
+                desc = _lib.MsmpTiles(tn, n_tiles, ptr(tile_node), ptr(tile_count), ptr(edge_slot))
+                self._tiles = (desc, tile_node, tile_count, edge_slot)      # the tensors keep the descriptor's memory alive
+                return self._tiles
+            tn = min(tn - 1, tn - (max_nodes - _lib.MSMP_TILE_NCAP)) if max_nodes > _lib.MSMP_TILE_NCAP else tn - 1
+        return None
 
     @property
     def tgt_long(self):

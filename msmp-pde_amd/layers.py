@@ -6,6 +6,8 @@ state_dict keys are identical (`message_net_1.0.weight` [128, 2*128+tw+1+nv], `m
 reference checkpoints load unchanged.  Parameters are created in float32 whatever the default dtype
 is (the reference's import side effect makes it float64, temporal/solvers.py:10).
 """
+import ctypes
+
 import torch
 from torch import nn
 
@@ -127,8 +129,9 @@ def _mp_layer_hip(h, u, pos_x, variables, gs, main, gate, eps, dense_message=Non
     mode = main.MODE | (_lib.MSMP_LAYER_DENSE_MESSAGE if dense else 0)
     ws_bytes = L.msmp_mp_layer_workspace_bytes(n, gs.n_edges, int(gated), gs.max_in_degree)
     ws = _Workspace.get(ws_bytes, h.device)
+    tiles = gs.tiles()
     check(L.msmp_mp_layer_f32(ptr(h), ptr(u), ptr(pos_x), ptr(variables), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt),
-                              ptr(gs.graph_ptr), n, gs.n_edges, gs.n_graphs, gs.max_in_degree, gs.max_graph_nodes, main.time_window,
+                              None if tiles is None else ctypes.byref(tiles[0]), ptr(gs.graph_ptr), n, gs.n_edges, gs.n_graphs, gs.max_in_degree, gs.max_graph_nodes, main.time_window,
                               main.n_variables,
                               ptr(main.packed()), ptr(gate.packed()) if gated else None, mode, eps, ptr(out),
                               ptr(ws), ws.numel(), current_stream()), 'msmp_mp_layer_f32')

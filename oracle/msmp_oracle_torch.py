@@ -17,8 +17,8 @@ def swish(x):                                   # experiments/models_gnn.py:20-2
 
 
 def _seg_mean(x, index, n):                     # PyG aggr='mean' / scatter-mean
-    out = torch.zeros(n, x.shape[1], dtype=x.dtype).index_add_(0, index, x)
-    cnt = torch.zeros(n, dtype=x.dtype).index_add_(0, index, torch.ones(index.numel(), dtype=x.dtype))
+    out = torch.zeros(n, x.shape[1], dtype=x.dtype, device=x.device).index_add_(0, index, x)
+    cnt = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, index, torch.ones(index.numel(), dtype=x.dtype, device=x.device))
     return out / cnt.clamp(min=1)[:, None]
 
 
@@ -47,7 +47,7 @@ def lem_forward(inputs, w, wz, bias, bz, dt=1.0, states=None):
     """See msmp_oracle.lem_forward (PARITY UNPINNED)."""
     t_len, n, _ = inputs.shape
     nh = wz.shape[0]
-    y, z = (torch.zeros(n, nh, dtype=inputs.dtype), torch.zeros(n, nh, dtype=inputs.dtype)) if states is None else states
+    y, z = (torch.zeros(n, nh, dtype=inputs.dtype, device=inputs.device), torch.zeros(n, nh, dtype=inputs.dtype, device=inputs.device)) if states is None else states
     for t in range(t_len):
         g = F.linear(torch.cat((y, inputs[t]), 1), w, bias)
         dt_bar = dt * torch.sigmoid(g[:, :nh])
@@ -58,27 +58,28 @@ def lem_forward(inputs, w, wz, bias, bz, dt=1.0, states=None):
 
 
 def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=6, as_numpy=True, decoder_diff=False,
-                   lem_initial_states=None):
+                   lem_initial_states=None, dtype=torch.float64, device='cpu'):
     """forward(data) of the six in-scope solver classes (see msmp_oracle.solver_forward for the line map).
     `sd` values may be float64 torch tensors that require grad (as_numpy=False keeps the autograd graph:
-    used to check the product's gradients)."""
-    t64 = lambda a: a.to(torch.float64) if torch.is_tensor(a) else torch.as_tensor(a).to(torch.float64)
+    used to check the product's gradients).  dtype / device: float64 on the CPU is the oracle; the tests also evaluate it
+    in float32 on the GPU (PyTorch-ROCm, rocBLAS GEMMs) as a second measurement of what float32 arithmetic can deliver."""
+    t64 = lambda a: (a if torch.is_tensor(a) else torch.as_tensor(a)).to(device=device, dtype=dtype)
     sd = {k: t64(v) for k, v in sd.items()}
     tw = time_window
     if kind == 'MSSMP_PDE_Solver':
         sub = lambda pre: solver_forward('MP_PDE_SolverLEMLinGated', {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)},
-                                         data, pde, tw, eq_variables, hidden_layer, as_numpy=False, decoder_diff=True)
+                                         data, pde, tw, eq_variables, hidden_layer, as_numpy=False, decoder_diff=True, dtype=dtype, device=device)
         scale, diff = sub('scale.'), sub('diff.')
-        dt = torch.cumsum(torch.ones(tw, dtype=torch.float64) * pde.dt, 0)
+        dt = torch.cumsum(torch.ones(tw, dtype=dtype, device=device) * pde.dt, 0)
         out = (1.0 - scale) * t64(data.x)[:, -1:] + dt[None, :] * (scale * diff)
-        return out.detach().numpy() if as_numpy else out
+        return out.detach().cpu().numpy() if as_numpy else out
     two_d = kind in O.KINDS_2D
     u = t64(data.x)
-    ei = torch.as_tensor(data.edge_index).long()
-    batch = torch.as_tensor(data.batch).long()
+    ei = torch.as_tensor(data.edge_index).long().to(device)
+    batch = torch.as_tensor(data.batch).long().to(device)
     b = int(batch.max()) + 1
     pos_x, pos_t, variables = (t64(a) for a in O.build_variables(kind, data, pde, eq_variables))
-    dt = torch.cumsum(torch.ones(tw, dtype=torch.float64) * pde.dt, 0)
+    dt = torch.cumsum(torch.ones(tw, dtype=dtype, device=device) * pde.dt, 0)
     if 'LEM' in kind or 'LSTM' in kind:
         if two_d:
             ts = dt[None, :] + pos_t
@@ -89,7 +90,7 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
         if 'LSTM' in kind:
             r = 'embedding_lstm.rnn.'
             x, nh = torch.stack(steps, 0), sd[r + 'weight_hh_l0'].shape[1]
-            h = torch.zeros(x.shape[1], nh, dtype=x.dtype)
+            h = torch.zeros(x.shape[1], nh, dtype=x.dtype, device=x.device)
             c = torch.zeros_like(h)
             for t in range(x.shape[0]):
                 g = F.linear(x[t], sd[r + 'weight_ih_l0'], sd[r + 'bias_ih_l0']) + F.linear(h, sd[r + 'weight_hh_l0'], sd[r + 'bias_hh_l0'])
@@ -128,4 +129,4 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
         diff = F.conv1d(swish(F.conv1d(h[:, None, :], sd['output_mlp.0.weight'], sd['output_mlp.0.bias'], stride=s1)),
                         sd['output_mlp.2.weight'], sd['output_mlp.2.bias'])[:, 0, :]
         out = diff if decoder_diff else u[:, -1:] + dt[None, :] * diff
-    return out.detach().numpy() if as_numpy else out
+    return out.detach().cpu().numpy() if as_numpy else out

@@ -63,9 +63,22 @@ def run(bsz):
                                                                        tw, nv, ptr(packed), ptr(agg), cs()), 'edge')
     t_proj = timed(proj)
     t_real = timed(edge(gs.col, gs.tgt))
+    tiles = gs.tiles()
+    t_staged = t_fold = None
+    if tiles is not None:
+        import ctypes
+        tb = ctypes.byref(tiles[0])
+        staged = lambda: _lib.check(L.msmp_edge_aggregate_tiled_f32(None, None, None, None, ptr(P), ptr(Q), ptr(gs.rowptr), tb, n, e, tw, nv,
+                                                                     ptr(packed), ptr(agg), cs()), 'tiled')
+        folded = lambda: _lib.check(L.msmp_edge_aggregate_tiled_f32(ptr(h), ptr(u), ptr(pos), ptr(var), None, None, ptr(gs.rowptr), tb, n, e, tw, nv,
+                                                                     ptr(packed), ptr(agg), cs()), 'folded')
+        t_staged, t_folded = timed(staged), timed(folded)
     col64, tgt64 = (gs.col % 64).contiguous(), (gs.tgt % 64).contiguous()
     t_fold = timed(edge(col64, tgt64))
     print(f'{args.experiment} x{bsz}: N={n} E={e} max in-degree {gs.max_in_degree}')
+    if tiles is not None:
+        print(f'  tile kernel (tile_nodes {tiles[0].tile_nodes}): staged P/Q {t_staged:8.1f} us   folded projections {t_folded:8.1f} us   '
+              f'(gather kernels: proj + edge = {t_proj + t_real:.1f} us)')
     print(f'  node_proj                      {t_proj:8.1f} us   ({(n * 128 * 4 * 3 + n * (tw + 1 + nv) * 4) / t_proj / 1e3:.0f} GB/s algorithmic)')
     print(f'  edge+mean, real gathers        {t_real:8.1f} us')
     print(f'  edge+mean, gathers folded x64  {t_fold:8.1f} us   -> gather-miss latency share {100 * (1 - t_fold / t_real):.0f} %')

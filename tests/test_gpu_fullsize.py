@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import msmp_oracle as O
-from helpers import EXPERIMENTS, assert_parity
+from helpers import EXPERIMENTS, assert_parity, fp32_floors
 
 pytestmark = pytest.mark.gpu
 TW = 25
@@ -67,7 +67,7 @@ def test_full_size_batch_properties(mp, kind, exp, layers):
     sub, rows = subgraph(graph, ids, nx)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     ref = O.solver_forward(kind, sd, sub, c.pde, TW, c.eqv, layers)
-    floor = O.solver_forward(kind, sd, sub, c.pde, TW, c.eqv, layers, dtype=np.float32)
+    floor = fp32_floors(kind, sd, sub, c.pde, TW, c.eqv, layers)
     assert_parity('full_size_batch_properties', f'{kind}/{exp}/x{B}/depth{layers}', out[torch.as_tensor(rows, device='cuda')].double().cpu().numpy(),
                   ref, floor)
 

@@ -611,3 +611,109 @@ def test_guard_bands_are_active(mp):
     assert abs(float(t._base[0]) - 12345.678) < 1e-2 and abs(float(t._base[-1]) - 12345.678) < 1e-2
     u = torch.empty_like(t)
     assert u.storage_offset() == 256 and u.data_ptr() % 256 == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Node tiles (msmp_build_tiles) and the LDS-staged message kernel (msmp_edge_aggregate_tiled_f32)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _tile_case(mp, exp, bsz, nx=100, neighbors=3, seed=3):
+    from msmp_pde_amd.synthetic import make_case
+    from msmp_pde_amd.graph import structure_of
+    c = make_case(exp, bsz, seed=seed, device='cuda', nx=nx, neighbors=neighbors, dtype=torch.float64)
+    steps = [50] * bsz
+    data, labels = c.creator.create_data(c.u_super, steps)
+    graph = c.creator.create_graph(data, labels, c.x, c.variables, steps)
+    return c, graph, structure_of(graph)
+
+
+@pytest.mark.parametrize('exp,bsz,nx,neighbors', [('E2', 5, 100, 3), ('WE3', 4, 100, 3), ('RPU', 3, 100, 3), ('MSWG3', 2, 100, 8),
+                                                  ('E2', 7, 40, 3), ('E2', 1, 100, 2)])
+def test_node_tiles_are_a_valid_cover(mp, exp, bsz, nx, neighbors):
+    """msmp_build_tiles: every tile lists its target nodes first, then each further source exactly once; every edge's slot pair
+    points at its own target / source; lists stay within MSMP_TILE_NCAP and MSMP_TILE_EDGES (checked against a numpy rebuild)."""
+    from msmp_pde_amd import _lib
+    c, graph, gs = _tile_case(mp, exp, bsz, nx, neighbors)
+    t = gs.tiles()
+    assert t is not None, 'the banded 1-D graphs of the four experiments must tile'
+    desc, tile_node, tile_count, edge_slot = t
+    tn, n_tiles = desc.tile_nodes, desc.n_tiles
+    rowptr, col = gs.rowptr.cpu().numpy(), gs.col.cpu().numpy()[:gs.n_edges]
+    tile_node = tile_node.cpu().numpy().reshape(n_tiles, _lib.MSMP_TILE_NCAP)
+    tile_count, edge_slot = tile_count.cpu().numpy(), edge_slot.cpu().numpy()[:gs.n_edges]
+    assert n_tiles == -(-gs.n_nodes // tn)
+    for ti in range(n_tiles):
+        n0, n1 = ti * tn, min((ti + 1) * tn, gs.n_nodes)
+        e0, e1 = rowptr[n0], rowptr[n1]
+        assert e1 - e0 <= _lib.MSMP_TILE_EDGES and tile_count[ti] <= _lib.MSMP_TILE_NCAP
+        nodes = tile_node[ti]
+        assert np.array_equal(nodes[:n1 - n0], np.arange(n0, n1))
+        extra = nodes[n1 - n0:tile_count[ti]]
+        assert len(set(extra.tolist())) == len(extra) and not np.any((extra >= n0) & (extra < n1))
+        assert set(extra.tolist()) == set(col[e0:e1][(col[e0:e1] < n0) | (col[e0:e1] >= n1)].tolist())
+        assert np.all((nodes >= 0) & (nodes < gs.n_nodes))
+        tgt_of_edge = np.searchsorted(rowptr, np.arange(e0, e1), side='right') - 1
+        assert np.array_equal(n0 + (edge_slot[e0:e1] & 255), tgt_of_edge)
+        assert np.array_equal(nodes[(edge_slot[e0:e1] >> 8) & 255], col[e0:e1])
+
+
+def test_irregular_graph_does_not_tile(mp):
+    """A random graph whose tiles would need more than 32 distinct nodes reports None (the callers keep the gather kernels)."""
+    from msmp_pde_amd.graph import GraphStructure
+    rng = np.random.default_rng(5)
+    n, b = 600, 3
+    tgt = np.repeat(np.arange(n), 6)
+    src = rng.integers(0, 200, tgt.size) + 200 * (tgt // 200)
+    ei = torch.tensor(np.stack([src, tgt])).cuda()
+    gs = GraphStructure(ei, torch.arange(n).cuda() // 200, n)
+    assert gs.tiles() is None
+
+
+@pytest.mark.parametrize('exp,tw,nv,bsz,nx', [('E2', 25, 2, 9, 100), ('WE3', 25, 3, 5, 100), ('RPU', 50, 3, 4, 100), ('MSWG3', 50, 3, 3, 100),
+                                              ('E2', 25, 2, 3, 40), ('E2', 20, 1, 2, 100)])
+def test_tiled_message_kernel_vs_gather_kernels_and_oracle(mp, exp, tw, nv, bsz, nx):
+    """msmp_edge_aggregate_tiled_f32 (P / Q rows staged in LDS; and the folded form that projects P / Q inside the kernel)
+    against msmp_node_project_f32 + msmp_edge_aggregate_projected_f32 (same formulas; the tile kernel scales its activations by
+    2^6 ahead of the fp16 split, so the low-order bits differ) and against the float64 oracle within the kernel bar; repeated
+    launches are bitwise identical."""
+    import ctypes
+    from msmp_pde_amd._lib import check, ptr, current_stream
+    L = mp.lib()
+    c, graph, gs = _tile_case(mp, exp, bsz, nx)
+    t = gs.tiles()
+    assert t is not None
+    n, e = gs.n_nodes, gs.n_edges
+    rng = np.random.default_rng(11)
+    sd = rand_layer_sd(rng, tw, nv)
+    blob = pack(mp, sd, tw, nv)
+    h = torch.tensor(rng.standard_normal((n, H)), dtype=torch.float32).cuda()
+    u = torch.tensor(rng.standard_normal((n, tw)).cumsum(0) * 0.05, dtype=torch.float32).cuda()     # smooth along the grid like real data
+    pos = torch.tensor(rng.uniform(0, 1, n), dtype=torch.float32).cuda()
+    var = torch.tensor(rng.uniform(0, 1, (n, nv)), dtype=torch.float32).cuda()
+    P, Q = torch.empty(n, H, device='cuda'), torch.empty(n, H, device='cuda')
+    ref, staged, folded = (torch.empty(n, H, device='cuda') for _ in range(3))
+    st = current_stream()
+    check(L.msmp_node_project_f32(ptr(h), ptr(u), ptr(pos), ptr(var), n, tw, nv, ptr(blob), ptr(P), ptr(Q), st), 'proj')
+    check(L.msmp_edge_aggregate_projected_f32(ptr(P), ptr(Q), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt), n, e, gs.max_in_degree, tw, nv,
+                                              ptr(blob), ptr(ref), st), 'edge')
+    check(L.msmp_edge_aggregate_tiled_f32(None, None, None, None, ptr(P), ptr(Q), ptr(gs.rowptr), ctypes.byref(t[0]), n, e, tw, nv, ptr(blob),
+                                          ptr(staged), st), 'tiled staged')
+    check(L.msmp_edge_aggregate_tiled_f32(ptr(h), ptr(u), ptr(pos), ptr(var), None, None, ptr(gs.rowptr), ctypes.byref(t[0]), n, e, tw, nv,
+                                          ptr(blob), ptr(folded), st), 'tiled folded')
+    folded2 = torch.empty_like(folded)
+    check(L.msmp_edge_aggregate_tiled_f32(ptr(h), ptr(u), ptr(pos), ptr(var), None, None, ptr(gs.rowptr), ctypes.byref(t[0]), n, e, tw, nv,
+                                          ptr(blob), ptr(folded2), st), 'tiled folded')
+    torch.cuda.synchronize()
+    assert torch.equal(folded, folded2)
+    scale = ref.abs().max().item()
+    assert (staged - ref).abs().max().item() < 2e-6 * scale and (folded - ref).abs().max().item() < 2e-6 * scale
+    p64 = O.layer_params({k: v.astype(np.float64) for k, v in sd.items()}, '')
+    ei = np.stack([gs.col.cpu().numpy()[:e], gs.tgt.cpu().numpy()[:e]])
+    msg = O.edge_messages(p64, h.double().cpu().numpy(), u.double().cpu().numpy(), pos.double().cpu().numpy()[:, None],
+                          var.double().cpu().numpy(), ei)
+    agg = O.scatter_mean(msg, ei[1], n)
+    den = max(np.abs(agg).max(), 1e-30)
+    err = np.abs(folded.double().cpu().numpy() - agg).max() / den
+    err_st = np.abs(staged.double().cpu().numpy() - agg).max() / den
+    err_ga = np.abs(ref.double().cpu().numpy() - agg).max() / den
+    print(f'{exp} tw={tw}: relative max error vs float64 oracle: tile kernel folded {err:.2e}, staged {err_st:.2e}, gather kernels {err_ga:.2e}')
+    assert err < 1e-6 and err_st < 1e-6

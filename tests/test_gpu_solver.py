@@ -7,7 +7,7 @@ import torch
 
 from oracle import msmp_oracle as O
 from helpers import (load, sd_of, graph_of, pde_of, EXPERIMENTS, synthetic_case, DEEP_CASES, deep_state_dict, assert_parity, record_parity,
-                     err_stats)
+                     err_stats, fp32_floors)
 
 pytestmark = pytest.mark.gpu
 TW = 25
@@ -112,7 +112,7 @@ def test_full_depth_vs_reference_golden(mp, kind, exp):
     opde = pde_of(d)
     with torch.no_grad():
         out = model(data)
-    floor = O.solver_forward(kind, sd64, g, opde, TW, eqv, 6, dtype=np.float32)
+    floor = fp32_floors(kind, sd64, g, opde, TW, eqv, 6)
     assert_parity('full_depth_vs_reference_golden', f'{kind}/{exp}', out.double().cpu().numpy(), d['out'], floor)
     if int(d['n_roll']):
         gc = mp.GraphCreator(pde, neighbors=3, time_window=TW, device='cuda')
@@ -150,7 +150,7 @@ def test_full_depth_vs_oracle(mp, kind, exp):
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     g = case.graph_np()
     ref = O.solver_forward(kind, sd, g, case.pde, TW, case.eqv, 6)
-    floor = O.solver_forward(kind, sd, g, case.pde, TW, case.eqv, 6, dtype=np.float32)
+    floor = fp32_floors(kind, sd, g, case.pde, TW, case.eqv, 6)
     assert_parity('full_depth_vs_oracle', f'{kind}/{exp}', out.double().cpu().numpy(), ref, floor)     # bar: helpers.assert_parity
 
 
@@ -273,7 +273,7 @@ def test_large_neighbourhood_stress_vs_oracle(mp, neighbors):
     from types import SimpleNamespace
     g = SimpleNamespace(**{k: v.detach().cpu().numpy() for k, v in graph.__dict__.items() if torch.is_tensor(v)})
     ref = O.solver_forward('MP_PDE_Solver2DLEMLinGated', sd, g, c.pde, TW, c.eqv, 2)
-    floor = O.solver_forward('MP_PDE_Solver2DLEMLinGated', sd, g, c.pde, TW, c.eqv, 2, dtype=np.float32)
+    floor = fp32_floors('MP_PDE_Solver2DLEMLinGated', sd, g, c.pde, TW, c.eqv, 2)
     print(f'n={neighbors}: E/graph {ei_ref.shape[1] // 6}, max in-degree {deg.max()}')
     assert_parity('large_neighbourhood_stress', f'MSWG3/n={neighbors}', out.double().cpu().numpy(), ref, floor)
 
@@ -297,7 +297,7 @@ def test_other_grid_resolutions_vs_oracle(mp, nx):
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     g = SimpleNamespace(**{k: v.detach().cpu().numpy() for k, v in graph.__dict__.items() if torch.is_tensor(v)})
     ref = O.solver_forward(kind, sd, g, c.pde, TW, c.eqv, 2)
-    floor = O.solver_forward(kind, sd, g, c.pde, TW, c.eqv, 2, dtype=np.float32)
+    floor = fp32_floors(kind, sd, g, c.pde, TW, c.eqv, 2)
     with torch.no_grad():
         out = model.eval()(graph)
     assert_parity('other_grid_resolutions', f'{kind}/E2/nx={nx}', out.double().cpu().numpy(), ref, floor)

@@ -44,10 +44,12 @@ def test_argument_errors_are_reported_not_thrown(mp):
     L = mp.lib()
     rc = L.msmp_scatter_mean_f32(None, None, 10, None, None)
     assert rc == -1 and b'null pointer' in L.msmp_last_error()
-    rc = L.msmp_mp_layer_f32(*([None] * 8), 1, 1, 1, 6, 100, 25, 2, None, None, 0, 1e-5, None, None, 0, None)
+    rc = L.msmp_mp_layer_f32(*([None] * 9), 1, 1, 1, 6, 100, 25, 2, None, None, 0, 1e-5, None, None, 0, None)
     assert rc == -1
     # every new entry point of this round validates its arguments the same way (no device work happens on these calls)
     assert L.msmp_node_tail_f32(*([None] * 5), 10, 1, 100, 2, None, None, 1, 1e-5, None, None) == -1
+    assert L.msmp_build_tiles(None, None, 10, 20, 21, None, None, None, None, None) == -1
+    assert L.msmp_edge_aggregate_tiled_f32(*([None] * 8), 10, 20, 25, 2, None, None, None) == -1
     assert L.msmp_mlp2_swish_f32(None, 10, 28, None, None, None) == -1
     assert L.msmp_lem_encoder_nodes_f32(*([None] * 5), 10, 25, 2, 0, 1.0, None, 1, None, None) == -1
     assert L.msmp_decoder2d_f32(None, None, 10, 25, None, None, None, None, 0.016, None, None) == -1
@@ -56,8 +58,8 @@ def test_argument_errors_are_reported_not_thrown(mp):
     assert L.msmp_mp_layer_bwd_f32(*([None] * 9), 10, 20, 1, 25, 2, None, None, 1, 1e-5, None, None, None, None, 0, None) == -1
     assert L.msmp_mp_layer_bwd_workspace_bytes(0, 5, 25, 2, 1) == 0 and L.msmp_mp_layer_bwd_workspace_bytes(100, 588, 25, 2, 1) > 0
     # knobs: known keys are accepted, unknown ones rejected with a message
-    for key in (b'split', b'edge_nb', b'edge_occ', b'edge_ws', b'edge_xcd', b'tail', b'pair', b'lem', b'lem_nodes'):
-        assert L.msmp_tune(key, {b'split': 1, b'edge_occ': 2, b'tail': 1, b'lem': 3, b'lem_nodes': 1}.get(key, 0)) == 0, key
+    for key in (b'split', b'edge_nb', b'edge_occ', b'edge_ws', b'edge_xcd', b'tail', b'pair', b'lem', b'lem_nodes', b'tile'):
+        assert L.msmp_tune(key, {b'split': 1, b'edge_occ': 2, b'tail': 1, b'lem': 3, b'lem_nodes': 1, b'pair': 1, b'tile': 2}.get(key, 0)) == 0, key
     assert L.msmp_tune(b'no_such_knob', 1) != 0 and b'unknown key' in L.msmp_last_error()
 
 
