@@ -178,9 +178,13 @@ int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes,
 /* L1 + L2 on node tiles: same result as msmp_edge_aggregate_projected_f32 (p, q given: the tile's P / Q rows are staged in
  * LDS) or, with p == q == NULL, as msmp_node_project_f32 + msmp_edge_aggregate_projected_f32 in ONE launch: the tile's h / u /
  * pos / vars rows are staged in LDS, P and Q of the tile's nodes are computed there (halo nodes recomputed per tile) and never
- * touch HBM. */
-int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, const float* pos, const float* vars, const float* p,
-                                  const float* q, const int32_t* rowptr, const msmp_tiles_t* tiles, int64_t n_nodes,
+ * touch HBM.  feat (may be NULL): the packed [u | pos | vars] rows of msmp_pack_node_features_f32; they are the same for every
+ * layer of a forward, so packing them once saves each layer's tile staging the scalar loads of those columns. */
+int msmp_node_feature_stride(int tw, int nv);
+int msmp_pack_node_features_f32(const float* u, const float* pos, const float* vars, int64_t n_nodes, int tw, int nv,
+                                float* feat_out, msmp_stream_t stream);
+int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, const float* pos, const float* vars, const float* feat,
+                                  const float* p, const float* q, const int32_t* rowptr, const msmp_tiles_t* tiles, int64_t n_nodes,
                                   int64_t n_edges, int tw, int nv, const float* packed, float* agg_out, msmp_stream_t stream);
 
 /* L2  PyG aggr='mean' (torch_scatter scatter-mean; experiments/models_gnn.py:42,107):
@@ -225,11 +229,12 @@ int msmp_gate_blend_f32(const float* h, const float* gate_pre, const float* main
  * used, otherwise the message tensor goes through the workspace; max_graph_nodes as in
  * msmp_instance_norm_f32.  Workspace size from msmp_mp_layer_workspace_bytes (same max_in_degree).
  * tiles (may be NULL): node tiles of the structure (msmp_build_tiles); with them rows L1 + L2 run on the LDS-staged tile
- * kernel (msmp_edge_aggregate_tiled_f32, per-node projections folded in), without them on the gather kernels. */
+ * kernel (msmp_edge_aggregate_tiled_f32, per-node projections folded in), without them on the gather kernels; feat (may be
+ * NULL) as in msmp_edge_aggregate_tiled_f32. */
 size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges, int gated, int max_in_degree);
 int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars,
-                      const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const msmp_tiles_t* tiles,
-                      const int32_t* graph_ptr, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                      const float* feat, const int32_t* rowptr, const int32_t* col, const int32_t* tgt,
+                      const msmp_tiles_t* tiles, const int32_t* graph_ptr, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
                       int max_in_degree, int max_graph_nodes, int tw, int nv, const float* packed_main,
                       const float* packed_gate, int mode,
                       float eps, float* h_out, void* workspace, size_t workspace_bytes,

@@ -456,7 +456,7 @@ extern "C" size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges
     return msg + nod * 6 + 256;
 }
 
-extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars,
+extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars, const float* feat,
                                  const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const msmp_tiles_t* tiles,
                                  const int32_t* graph_ptr,
                                  int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int max_in_degree, int max_graph_nodes,
@@ -486,10 +486,10 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
     const int tile_mode = (tiles && n_edges > 0 && msmp_tune_get("split")) ? msmp_tune_get("tile") : 0;
     auto aggregate = [&](const float* packed, float* agg) -> int {
         if (fused && !dense && tile_mode == 2)       // node tiles staged in LDS, P / Q computed in the workgroup
-            return msmp_edge_aggregate_tiled_f32(h, u, pos, vars, nullptr, nullptr, rowptr, tiles, n_nodes, n_edges, tw, nv, packed, agg, stream);
+            return msmp_edge_aggregate_tiled_f32(h, u, pos, vars, feat, nullptr, nullptr, rowptr, tiles, n_nodes, n_edges, tw, nv, packed, agg, stream);
         if (fused && !dense && tile_mode == 1) {
             const int r = msmp_node_project_f32(h, u, pos, vars, n_nodes, tw, nv, packed, pbuf, qbuf, stream);
-            return r ? r : msmp_edge_aggregate_tiled_f32(nullptr, nullptr, nullptr, nullptr, pbuf, qbuf, rowptr, tiles, n_nodes, n_edges, tw,
+            return r ? r : msmp_edge_aggregate_tiled_f32(nullptr, nullptr, nullptr, nullptr, nullptr, pbuf, qbuf, rowptr, tiles, n_nodes, n_edges, tw,
                                                          nv, packed, agg, stream);
         }
         if (fused && !dense) {
@@ -507,7 +507,7 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
     if (msmp_tune_get("split") && msmp_tune_get("tail") && max_graph_nodes > 0 && max_graph_nodes <= 128) {
         rc = MSMP_ERR_UNSUPPORTED;
         if (gated && fused && !dense && tile_mode == 2 && msmp_tune_get("pair") && (msmp_tune_get("pair") == 2 || n_nodes <= 65536))
-            rc = msmp_edge_aggregate_tiled_pair(h, u, pos, vars, rowptr, tiles, n_nodes, n_edges, tw, nv, packed_gate, packed_main, pre_gate,
+            rc = msmp_edge_aggregate_tiled_pair(h, u, pos, vars, feat, rowptr, tiles, n_nodes, n_edges, tw, nv, packed_gate, packed_main, pre_gate,
                                                 agg, stream);      // small batches: both heads in one launch
         else if (gated && fused && !dense && !tile_mode)       // small batches: both heads per launch (projection, then message + mean)
             rc = msmp_pair_project_aggregate(h, u, pos, vars, rowptr, col, tgt, n_nodes, n_edges, max_in_degree, tw, nv, packed_gate,

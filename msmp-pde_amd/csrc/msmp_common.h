@@ -11,7 +11,7 @@ int msmp_pair_project_aggregate(const float* h, const float* u, const float* pos
                                 int nv, const float* packed_a, const float* packed_b, float* p_a, float* q_a, float* p_b, float* q_b,
                                 float* agg_a, float* agg_b, msmp_stream_t stream);   // mlp_kernels.hip, library-internal
     // current value of a msmp_tune switch ("split", "tail"); library-internal
-int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* pos, const float* vars, const int32_t* rowptr,
+int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* pos, const float* vars, const float* feat, const int32_t* rowptr,
                                    const msmp_tiles_t* tiles, int64_t n_nodes, int64_t n_edges, int tw, int nv, const float* packed_a,
                                    const float* packed_b, float* agg_a, float* agg_b, msmp_stream_t stream);   // tile_kernels.hip
 

@@ -20,8 +20,8 @@ namespace msmp {
 // every workgroup per phase, kept in registers and added to g_prof_tile once at the end.
 #if MSMP_PROF_TILE
 __device__ unsigned long long g_prof_tile[16];
-#define TPROF_DECL long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tp = __builtin_readcyclecounter();
-#define TPROF(i) do { const long long t_ = __builtin_readcyclecounter(); pacc[i] += t_ - tp; tp = t_; } while (0)
+#define TPROF_DECL unsigned pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned tp = (unsigned)__builtin_readcyclecounter();
+#define TPROF(i) do { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); pacc[i] += t_ - tp; tp = t_; } while (0)
 #define TPROF_FLUSH if (tid == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_prof_tile[i_], (unsigned long long)pacc[i_]);
 #else
 #define TPROF_DECL
@@ -107,12 +107,30 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
     }
 }
 
+// Per-node rows of the columns of message_net_1 that are not hidden state: [u (tw) | pos | vars (nv) | 0 ...], padded to whole
+// 32-column chunks.  They do not change over the layers of a forward, so they are packed once and every layer's tile staging
+// reads them with 16-byte loads (instead of tw + 1 + nv scalar loads with index arithmetic per node and layer).
+__global__ __launch_bounds__(256) void pack_features_kernel(const float* __restrict__ u, const float* __restrict__ pos,
+                                                            const float* __restrict__ vars, long n, int tw, int nv, int stride,
+                                                            float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * stride) return;
+    const long node = i / stride;
+    const int k = (int)(i - node * stride);
+    float v = 0.f;
+    if (k < tw) v = u[node * tw + k];
+    else if (k == tw) v = pos[node];
+    else if (k <= tw + nv) v = vars[node * nv + (k - tw - 1)];
+    out[i] = v;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 struct TileArgs {
     const float* h;        // FOLD
     const float* u;
     const float* pos;
     const float* vars;
+    const float* feat;     // FOLD, optional: [N][32 * tail chunks] = [u | pos | vars | 0...] per node (msmp_pack_node_features_f32)
     const float* P;        // !FOLD
     const float* Q;
     const int* rowptr;
@@ -130,14 +148,19 @@ struct TileArgs {
     float* agg;
 };
 
-template <bool FOLD>
-__device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
+// MODE 0: staged P / Q rows;  1: folded projections, features read from u / pos / vars;  2: folded, packed feature rows
+template <int MODE>
+__device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, int n_tiles) {
+    constexpr bool FOLD = MODE != 0;
     float* wbuf = lds;                               // W2 chunks (2 x 16 KB) / epilogue staging / (FOLD) fragment tile
     float* pl = lds + WBUF_FLOATS;                   // P rows [32][PQLD]
     float* ql = pl + TILE_NCAP * PQLD;               // Q rows [32][PQLD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
+    TPROF_DECL
+    constexpr bool packed_feat = MODE == 2;          // [u | pos | vars] rows packed once per forward (msmp_pack_node_features_f32)
     const int tile = blockIdx.x;
+    (void)n_tiles;
     const int tile_n0 = tile * a.tile_nodes;
     const int tile_n1 = (int)min((long)tile_n0 + a.tile_nodes, a.n_nodes);
     const int tile_e0 = a.rowptr[tile_n0], tile_e1 = a.rowptr[tile_n1];
@@ -151,7 +174,6 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
     const float* prow = pl + (sl & 255) * PQLD + 4 * hh;
     const float* qrow = ql + ((sl >> 8) & 255) * PQLD + 4 * hh;
 
-    TPROF_DECL
     WStage ws;
     wstage_load(ws, a.w2s, tid);                     // W2 chunk 0, stored once the staging region is free
 
@@ -193,16 +215,28 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
             // tail features of (node = tid >> 3, columns 4 g .. 4 g + 3 of every tail chunk), g = tid & 7
             const int tn = tnode[tid >> 3];
             const int g = tid & 7;
-            float tx[2][4];
+            float tx[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (packed_feat) {  // packed per-node feature rows (same for all layers of a forward): one 16-byte load per tail chunk
 #pragma unroll
-            for (int jc = 0; jc < 2; ++jc)
+                for (int jc = 0; jc < 2; ++jc)
+                    if (jc < ntail) {
+                        const f32x4 fv = *reinterpret_cast<const f32x4*>(a.feat + (size_t)tn * (32 * ntail) + 32 * jc + 4 * g);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int k = 32 * jc + 4 * g + m;
-                    const float uv = a.u[(size_t)tn * a.tw + min(k, a.tw - 1)];
-                    const float vv = a.vars[(size_t)tn * a.nv + min(max(k - a.tw - 1, 0), a.nv - 1)];
-                    tx[jc][m] = k < a.tw ? uv : (k == a.tw ? a.pos[tn] : (k <= a.tw + a.nv ? vv : 0.f));
-                }
+                        for (int m = 0; m < 4; ++m) tx[jc][m] = fv[m];
+                    }
+            } else {
+#pragma unroll
+                for (int jc = 0; jc < 2; ++jc)
+                    if (jc < ntail) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const int k = 32 * jc + 4 * g + m;
+                            const float uv = a.u[(size_t)tn * a.tw + min(k, a.tw - 1)];
+                            const float vv = a.vars[(size_t)tn * a.nv + min(max(k - a.tw - 1, 0), a.nv - 1)];
+                            tx[jc][m] = k < a.tw ? uv : (k == a.tw ? a.pos[tn] : (k <= a.tw + a.nv ? vv : 0.f));
+                        }
+                    }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = tid + 256 * i;
@@ -257,8 +291,13 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
             for (int r = 0; r < 16; ++r) { accP[r] = bv; accQ[r] = 0.f; }
         }
         // fragment (s, plane) of chunk `ch`, row tile `wave`: lane-linear 16 bytes
+        // one 32-bit lane offset + a uniform base per fragment (scalar base + vector offset addressing): written as 40 separate
+        // 64-bit pointers the loop-invariant addresses were hoisted out of the tile loop and spilled
+        unsigned woff = (unsigned)((wave * 2 * 64 + lane) * 16);
+        asm volatile("" : "+v"(woff));
         auto wfrag = [&](int ch, int s, int plane) {
-            return reinterpret_cast<const half8*>(a.w1s + (size_t)ch * SPLIT_CHUNK_FLOATS)[((s * 4 + wave) * 2 + plane) * 64 + lane];
+            const char* base = reinterpret_cast<const char*>(a.w1s) + (size_t)ch * (SPLIT_CHUNK_FLOATS * 4) + (s * 8 + plane) * 1024;
+            return *reinterpret_cast<const half8*>(base + woff);
         };
         auto afrag = [&](int ch, half8 (&ahi)[2], half8 (&alo)[2]) {
             const _Float16* row = bt + (ch * 32 + c) * BROW_T + 8 * hh;
@@ -273,34 +312,37 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, whi, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi, acc, 0, 0, 0);
         };
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            half8 wp[2][2], wq[2][2];
+        // weight fragments are requested one chunk ahead of the MFMAs that use them (they come from L2: ~1 us away)
+        half8 wp[2][2][2], wq[2][2][2];               // [buffer][K = 16 step][plane]
+        auto wload = [&](int buf, int chp, int chq) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) { wp[s][p] = wfrag(ch, s, p); wq[s][p] = wfrag(4 + ch, s, p); }
+                for (int p = 0; p < 2; ++p) { wp[buf][s][p] = wfrag(chp, s, p); wq[buf][s][p] = wfrag(chq, s, p); }
+        };
+        wload(0, 0, 4);
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const int cur = ch & 1;
+            if (ch < 3) wload(cur ^ 1, ch + 1, 5 + ch);
+            else if (ntail > 0) wload(cur ^ 1, 8, 8 + (ntail > 1 ? 1 : 0));          // tail chunk(s): wp <- chunk 8, wq <- chunk 9 (tw = 50)
             half8 ahi[2], alo[2];
             afrag(ch, ahi, alo);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                mma3(accP, ahi[s], alo[s], wp[s][0], wp[s][1]);
-                mma3(accQ, ahi[s], alo[s], wq[s][0], wq[s][1]);
+                mma3(accP, ahi[s], alo[s], wp[cur][s][0], wp[cur][s][1]);
+                mma3(accQ, ahi[s], alo[s], wq[cur][s][0], wq[cur][s][1]);
             }
         }
         for (int jc = 0; jc < ntail; ++jc) {
-            half8 wt[2][2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) wt[s][p] = wfrag(8 + jc, s, p);
             half8 phi[2], plo[2], qhi[2], qlo[2];
             afrag(4 + 2 * jc, phi, plo);
             afrag(5 + 2 * jc, qhi, qlo);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                mma3(accP, phi[s], plo[s], wt[s][0], wt[s][1]);
-                mma3(accQ, qhi[s], qlo[s], wt[s][0], wt[s][1]);
+            for (int s = 0; s < 2; ++s) {          // buffer 0 after the four h chunks: wp = chunk 8, wq = chunk 9 (or 8 again)
+                const half8 whi = jc == 0 ? wp[0][s][0] : wq[0][s][0], wlo = jc == 0 ? wp[0][s][1] : wq[0][s][1];
+                mma3(accP, phi[s], plo[s], whi, wlo);
+                mma3(accQ, qhi[s], qlo[s], whi, wlo);
             }
         }
         TPROF(1);
@@ -379,21 +421,20 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
         const int par = t & 1;
         if (t < 3) wstage_load(ws, a.w2s + (size_t)(t + 1) * SPLIT_CHUNK_FLOATS, tid);
         const half8* w = reinterpret_cast<const half8*>(wbuf + par * SPLIT_CHUNK_FLOATS) + lane;
-        half8 ahi[2][4], alo[2][4];
+        // A fragments (hi, lo) of group g = (K step g >> 2, row tile g & 3): all 16 requested up front
+        half8 ahi[8], alo[8];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int T = 0; T < 4; ++T) {
-                ahi[s][T] = w[((s * 4 + T) * 2 + 0) * 64];
-                alo[s][T] = w[((s * 4 + T) * 2 + 1) * 64];
-            }
+        for (int g = 0; g < 8; ++g) {
+            ahi[g] = w[(g * 2 + 0) * 64];
+            alo[g] = w[(g * 2 + 1) * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int s = g >> 2, T = g & 3;
-            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[s][T], bhi[par][s], y[T], 0, 0, 0);
-            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s][T], blo[par][s], y[T], 0, 0, 0);
-            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s][T], bhi[par][s], y[T], 0, 0, 0);
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[g], bhi[par][s], y[T], 0, 0, 0);
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[g], blo[par][s], y[T], 0, 0, 0);
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[g], bhi[par][s], y[T], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (t < 3) {
                 act_slice(g);
@@ -468,11 +509,13 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
     TPROF(7);
     __syncthreads();
     TPROF(8);
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 4; ++k) {
         const int node = tile_n0 + nslot + 8 * k;
         if (node < tile_n1) {
-            const int r0 = r0b[k], r1 = r1b[k], deg = r1 - r0;
+            const int r0 = k == 0 ? r0b[0] : k == 1 ? r0b[1] : k == 2 ? r0b[2] : r0b[3];
+            const int r1 = k == 0 ? r1b[0] : k == 1 ? r1b[1] : k == 2 ? r1b[2] : r1b[3];
+            const int deg = r1 - r0;
             f32x4 sum = {0.f, 0.f, 0.f, 0.f};
             if (deg > 0) {
                 for (int rb = r0; rb < r1; rb += 8) {
@@ -495,10 +538,10 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
     TPROF_FLUSH
 }
 
-template <bool FOLD>
-__global__ __launch_bounds__(256, 2) void edge_tile_kernel(TileArgs a) {
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void edge_tile_kernel(TileArgs a, int n_tiles) {
     __shared__ __attribute__((aligned(16))) float lds[TILE_LDS_FLOATS];
-    edge_tile_body<FOLD>(a, lds);
+    edge_tile_body<MODE>(a, lds, n_tiles);
 }
 
 // Both heads of a gated pair in ONE launch (blockIdx.y = head; same body, bit-identical results): small batches are bound by the
@@ -506,9 +549,10 @@ __global__ __launch_bounds__(256, 2) void edge_tile_kernel(TileArgs a) {
 struct TileArgs2 {
     TileArgs head[2];
 };
-__global__ __launch_bounds__(256, 2) void edge_tile_pair_kernel(TileArgs2 a) {
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void edge_tile_pair_kernel(TileArgs2 a, int n_tiles) {
     __shared__ __attribute__((aligned(16))) float lds[TILE_LDS_FLOATS];
-    edge_tile_body<true>(a.head[blockIdx.y], lds);
+    edge_tile_body<MODE>(a.head[blockIdx.y], lds, n_tiles);
 }
 
 }  // namespace msmp
@@ -521,6 +565,27 @@ extern "C" __attribute__((visibility("default"))) int msmp_debug_prof_tile(unsig
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof_tile), 16 * sizeof(unsigned long long));
 }
 #endif
+
+// One tile per workgroup.  (Persistent workgroups, two per CU, that request the next tile's rows during the current tile's matrix
+// phase were built and measured in round 2: 6.81 vs 6.71 ms per rollout step, i.e. slower -- the dispatcher's own refill of a CU
+// as soon as a workgroup retires overlaps tiles better than a loop with a barrier at its end, and the prefetch registers spill.)
+static unsigned tile_grid(int n_tiles, int heads) { (void)heads; return (unsigned)n_tiles; }
+
+extern "C" int msmp_node_feature_stride(int tw, int nv) {
+    if (tw <= 0 || nv < 1 || nv > MSMP_MAX_VARS) return -1;
+    return 32 * tail_chunks(tw, nv);
+}
+
+extern "C" int msmp_pack_node_features_f32(const float* u, const float* pos, const float* vars, int64_t n_nodes, int tw, int nv,
+                                           float* feat_out, msmp_stream_t stream) {
+    MSMP_REQUIRE(u && pos && vars && feat_out, MSMP_ERR_ARG, "msmp_pack_node_features_f32: null pointer");
+    const int stride = msmp_node_feature_stride(tw, nv);
+    MSMP_REQUIRE(n_nodes > 0 && stride > 0, MSMP_ERR_ARG, "msmp_pack_node_features_f32: bad sizes");
+    const long total = (long)n_nodes * stride;
+    hipLaunchKernelGGL(pack_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, pos, vars,
+                       (long)n_nodes, tw, nv, stride, feat_out);
+    return check_launch("pack_features_kernel");
+}
 
 extern "C" int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int64_t n_edges, int tile_nodes,
                                 int32_t* tile_node_out, int32_t* tile_count_out, int32_t* edge_slot_out, int32_t* stats_out,
@@ -537,8 +602,8 @@ extern "C" int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64
     return check_launch("build_tiles_kernel");
 }
 
-extern "C" int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, const float* pos, const float* vars, const float* p,
-                                             const float* q, const int32_t* rowptr, const msmp_tiles_t* tiles, int64_t n_nodes,
+extern "C" int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, const float* pos, const float* vars, const float* feat,
+                                             const float* p, const float* q, const int32_t* rowptr, const msmp_tiles_t* tiles, int64_t n_nodes,
                                              int64_t n_edges, int tw, int nv, const float* packed, float* agg_out,
                                              msmp_stream_t stream) {
     MSMP_REQUIRE(rowptr && tiles && packed && agg_out, MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: null pointer");
@@ -554,18 +619,20 @@ extern "C" int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, con
     MSMP_REQUIRE(msmp_tune_get("split"), MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_f32: only on the fp16-split matrix path");
     const PackedLayout L = packed_layout(tw, nv);
     MSMP_REQUIRE(!fold || L.nc1 - 8 <= 2, MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_f32: tw + 1 + nv <= 64");
-    TileArgs a{h, u, pos, vars, p, q, rowptr, tiles->tile_node, tiles->tile_count, tiles->edge_slot, (long)n_nodes, (long)n_edges,
+    TileArgs a{h, u, pos, vars, feat, p, q, rowptr, tiles->tile_node, tiles->tile_count, tiles->edge_slot, (long)n_nodes, (long)n_edges,
                tiles->tile_nodes, tw, nv, L.nc1, packed + L.w1s, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, agg_out};
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_EDGE_MLP, st);
-    if (fold) hipLaunchKernelGGL(edge_tile_kernel<true>, dim3((unsigned)tiles->n_tiles), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(edge_tile_kernel<false>, dim3((unsigned)tiles->n_tiles), dim3(256), 0, st, a);
+    const dim3 grid(tile_grid(tiles->n_tiles, 1));
+    if (fold && feat) hipLaunchKernelGGL(edge_tile_kernel<2>, grid, dim3(256), 0, st, a, (int)tiles->n_tiles);
+    else if (fold) hipLaunchKernelGGL(edge_tile_kernel<1>, grid, dim3(256), 0, st, a, (int)tiles->n_tiles);
+    else hipLaunchKernelGGL(edge_tile_kernel<0>, grid, dim3(256), 0, st, a, (int)tiles->n_tiles);
     timing_end(MSMP_K_EDGE_MLP, st);
     return check_launch("edge_tile_kernel");
 }
 
 // Rows L1 + L2 of BOTH heads of a gated pair in one launch (library-internal; msmp_mp_layer_f32 at small batches).
-int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* pos, const float* vars, const int32_t* rowptr,
+int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* pos, const float* vars, const float* feat, const int32_t* rowptr,
                                    const msmp_tiles_t* tiles, int64_t n_nodes, int64_t n_edges, int tw, int nv, const float* packed_a,
                                    const float* packed_b, float* agg_a, float* agg_b, msmp_stream_t stream) {
     MSMP_REQUIRE(h && u && pos && vars && rowptr && tiles && packed_a && packed_b && agg_a && agg_b, MSMP_ERR_ARG,
@@ -576,12 +643,14 @@ int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* 
     const float* packed[2] = {packed_a, packed_b};
     float* agg[2] = {agg_a, agg_b};
     for (int i = 0; i < 2; ++i)
-        a2.head[i] = TileArgs{h, u, pos, vars, nullptr, nullptr, rowptr, tiles->tile_node, tiles->tile_count, tiles->edge_slot, (long)n_nodes,
+        a2.head[i] = TileArgs{h, u, pos, vars, feat, nullptr, nullptr, rowptr, tiles->tile_node, tiles->tile_count, tiles->edge_slot, (long)n_nodes,
                               (long)n_edges, tiles->tile_nodes, tw, nv, L.nc1, packed[i] + L.w1s, packed[i] + L.w2s, packed[i] + L.scales,
                               packed[i] + L.b1, packed[i] + L.b2, agg[i]};
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_EDGE_MLP, st);
-    hipLaunchKernelGGL(edge_tile_pair_kernel, dim3((unsigned)tiles->n_tiles, 2), dim3(256), 0, st, a2);
+    const dim3 grid(tile_grid(tiles->n_tiles, 2), 2);
+    if (feat) hipLaunchKernelGGL(edge_tile_pair_kernel<2>, grid, dim3(256), 0, st, a2, (int)tiles->n_tiles);
+    else hipLaunchKernelGGL(edge_tile_pair_kernel<1>, grid, dim3(256), 0, st, a2, (int)tiles->n_tiles);
     timing_end(MSMP_K_EDGE_MLP, st);
     return check_launch("edge_tile_pair_kernel");
 }

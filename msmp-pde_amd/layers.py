@@ -119,7 +119,19 @@ def _f32c(t):
 DENSE_MESSAGE = False     # True: evaluate message_net_1 on the per-edge concatenation (reference order of operations)
 
 
-def _mp_layer_hip(h, u, pos_x, variables, gs, main, gate, eps, dense_message=None):
+def node_features(u, pos_x, variables):
+    """[u | pos | vars | 0-pad] rows of msmp_pack_node_features_f32: the columns of message_net_1's input that are the same for
+    every layer of a forward.  Packed once per forward by the solvers and handed to every layer call (`feat`)."""
+    L = lib()
+    n, tw, nv = u.shape[0], u.shape[1], variables.shape[1]
+    stride = L.msmp_node_feature_stride(tw, nv)
+    feat = torch.empty(n, stride, dtype=torch.float32, device=u.device)
+    check(L.msmp_pack_node_features_f32(ptr(u), ptr(pos_x), ptr(variables), n, tw, nv, ptr(feat), current_stream()),
+          'msmp_pack_node_features_f32')
+    return feat
+
+
+def _mp_layer_hip(h, u, pos_x, variables, gs, main, gate, eps, dense_message=None, feat=None):
     """The HIP call proper (no autograd): msmp_mp_layer_f32."""
     L = lib()
     n = h.shape[0]
@@ -130,7 +142,7 @@ def _mp_layer_hip(h, u, pos_x, variables, gs, main, gate, eps, dense_message=Non
     ws_bytes = L.msmp_mp_layer_workspace_bytes(n, gs.n_edges, int(gated), gs.max_in_degree)
     ws = _Workspace.get(ws_bytes, h.device)
     tiles = gs.tiles()
-    check(L.msmp_mp_layer_f32(ptr(h), ptr(u), ptr(pos_x), ptr(variables), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt),
+    check(L.msmp_mp_layer_f32(ptr(h), ptr(u), ptr(pos_x), ptr(variables), ptr(feat), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt),
                               None if tiles is None else ctypes.byref(tiles[0]), ptr(gs.graph_ptr), n, gs.n_edges, gs.n_graphs, gs.max_in_degree, gs.max_graph_nodes, main.time_window,
                               main.n_variables,
                               ptr(main.packed()), ptr(gate.packed()) if gated else None, mode, eps, ptr(out),
@@ -138,7 +150,7 @@ def _mp_layer_hip(h, u, pos_x, variables, gs, main, gate, eps, dense_message=Non
     return out
 
 
-def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense_message=None):
+def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense_message=None, feat=None):
     """One message-passing layer (or one gated pair) on the device through msmp_mp_layer_f32.
     h [N,128], u [N,Tw], pos_x [N,1] or [N], variables [N,nv]: float32 CUDA tensors.
     dense_message: None -> module default (factorised message_net_1); True -> literal per-edge GEMM.
@@ -153,7 +165,7 @@ def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense
     assert n == gs.n_nodes and hd.shape[1] == HIDDEN and u.shape[1] == main.time_window
     assert variables.shape[1] == main.n_variables and pos_x.numel() == n
     if not need_grad:
-        return _mp_layer_hip(hd, u, pos_x, variables, gs, main, gate, eps, dense_message)
+        return _mp_layer_hip(hd, u, pos_x, variables, gs, main, gate, eps, dense_message, feat)
     from .autograd import MPLayerFunction
     params = list(main._params8()) + (list(gate._params8()) if gate is not None else [])
     hin = h if (h.dtype == torch.float32 and h.is_contiguous()) else h.to(torch.float32).contiguous()

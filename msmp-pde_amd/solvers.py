@@ -22,7 +22,7 @@ from torch import nn
 
 from ._lib import lib, check, ptr, current_stream, PARAM_EPOCH
 from .graph import structure_of
-from .layers import GNN_Layer, GNN_LayerLin, Swish, mp_layer
+from .layers import GNN_Layer, GNN_LayerLin, Swish, mp_layer, node_features
 from .lem import LEM, LEMS
 
 _DECODER = {20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}   # models_gnn.py:210-224; models_gnn2D.py:79-88
@@ -222,12 +222,14 @@ class _SolverBase(nn.Module):
         dt = torch.cumsum(torch.ones(tw, dtype=torch.float32, device=u.device) * self.pde.dt, 0)
 
         h = self._encode(u, pos_x, pos_t, variables, dt)
+        # the [u | pos | vars] columns of message_net_1's input do not change over the layers: packed once for the tile kernel
+        feat = node_features(u, pos_x.reshape(-1).contiguous(), variables.contiguous()) if (not torch.is_grad_enabled() and gs.tiles() is not None) else None
         for i in range(self.hidden_layer):
             if self.G2:
                 h = self._g2_pair(h, u, pos_x, variables, gs, i)
                 continue
             gate = self.gnn_layers_gate[i] if self.GATED else None
-            h = mp_layer(h, u, pos_x, variables, gs, self.gnn_layers[i], gate)
+            h = mp_layer(h, u, pos_x, variables, gs, self.gnn_layers[i], gate, feat=feat)
 
         grad_path = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.output_mlp.parameters()))
         if self.TWO_D and grad_path:    # models_gnn2D.py:125-141

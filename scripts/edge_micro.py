@@ -57,6 +57,9 @@ def run(bsz):
     agg = torch.empty(n, 128, device='cuda')
     proj = lambda: _lib.check(L.msmp_node_project_f32(ptr(h), ptr(u), ptr(pos), ptr(var), n, tw, nv, ptr(packed), ptr(P), ptr(Q), cs()), 'proj')
     proj()
+    from msmp_pde_amd.layers import node_features
+    global FEAT
+    FEAT = node_features(u, pos, var)
 
     def edge(col, tgt):
         return lambda: _lib.check(L.msmp_edge_aggregate_projected_f32(ptr(P), ptr(Q), ptr(gs.rowptr), ptr(col), ptr(tgt), n, e, gs.max_in_degree,
@@ -68,9 +71,9 @@ def run(bsz):
     if tiles is not None:
         import ctypes
         tb = ctypes.byref(tiles[0])
-        staged = lambda: _lib.check(L.msmp_edge_aggregate_tiled_f32(None, None, None, None, ptr(P), ptr(Q), ptr(gs.rowptr), tb, n, e, tw, nv,
+        staged = lambda: _lib.check(L.msmp_edge_aggregate_tiled_f32(None, None, None, None, None, ptr(P), ptr(Q), ptr(gs.rowptr), tb, n, e, tw, nv,
                                                                      ptr(packed), ptr(agg), cs()), 'tiled')
-        folded = lambda: _lib.check(L.msmp_edge_aggregate_tiled_f32(ptr(h), ptr(u), ptr(pos), ptr(var), None, None, ptr(gs.rowptr), tb, n, e, tw, nv,
+        folded = lambda: _lib.check(L.msmp_edge_aggregate_tiled_f32(ptr(h), ptr(u), ptr(pos), ptr(var), ptr(FEAT), None, None, ptr(gs.rowptr), tb, n, e, tw, nv,
                                                                      ptr(packed), ptr(agg), cs()), 'folded')
         t_staged, t_folded = timed(staged), timed(folded)
     col64, tgt64 = (gs.col % 64).contiguous(), (gs.tgt % 64).contiguous()

@@ -23,11 +23,13 @@ h = torch.randn(n, 128, device='cuda'); u = graph.x.float().contiguous(); pos = 
 P = torch.empty(n, 128, device='cuda'); Q = torch.empty(n, 128, device='cuda'); agg = torch.empty(n, 128, device='cuda')
 _lib.check(L.msmp_node_project_f32(ptr(h), ptr(u), ptr(pos), ptr(var), n, 25, 2, ptr(packed), ptr(P), ptr(Q), cs()), 'proj')
 tiles = gs.tiles(); tb = ctypes.byref(tiles[0])
+from msmp_pde_amd.layers import node_features
+FEAT = node_features(u, pos, var)
 names = ['prologue: index + row loads, staging, barrier', 'projection MFMAs (fold)', 'P/Q to LDS + barriers (fold)', 'first activation chunk + gathers',
          'chunk: MFMAs + activation of next (x4)', 'chunk: weight store + barrier (x4)', 'epilogue barrier A (x2)', 'epilogue swish + stage (x2)',
          'epilogue barrier B (x2)', 'segmented mean + store (x2)']
 for fold in (False, True):
-    args = (ptr(h), ptr(u), ptr(pos), ptr(var), None, None) if fold else (None, None, None, None, ptr(P), ptr(Q))
+    args = (ptr(h), ptr(u), ptr(pos), ptr(var), ptr(FEAT), None, None) if fold else (None, None, None, None, None, ptr(P), ptr(Q))
     run = lambda: _lib.check(L.msmp_edge_aggregate_tiled_f32(*args, ptr(gs.rowptr), tb, n, e, 25, 2, ptr(packed), ptr(agg), cs()), 'tiled')
     run(); torch.cuda.synchronize()
     L.msmp_debug_prof_tile(None, 1)

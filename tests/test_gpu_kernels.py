@@ -695,13 +695,18 @@ def test_tiled_message_kernel_vs_gather_kernels_and_oracle(mp, exp, tw, nv, bsz,
     check(L.msmp_node_project_f32(ptr(h), ptr(u), ptr(pos), ptr(var), n, tw, nv, ptr(blob), ptr(P), ptr(Q), st), 'proj')
     check(L.msmp_edge_aggregate_projected_f32(ptr(P), ptr(Q), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt), n, e, gs.max_in_degree, tw, nv,
                                               ptr(blob), ptr(ref), st), 'edge')
-    check(L.msmp_edge_aggregate_tiled_f32(None, None, None, None, ptr(P), ptr(Q), ptr(gs.rowptr), ctypes.byref(t[0]), n, e, tw, nv, ptr(blob),
+    check(L.msmp_edge_aggregate_tiled_f32(None, None, None, None, None, ptr(P), ptr(Q), ptr(gs.rowptr), ctypes.byref(t[0]), n, e, tw, nv, ptr(blob),
                                           ptr(staged), st), 'tiled staged')
-    check(L.msmp_edge_aggregate_tiled_f32(ptr(h), ptr(u), ptr(pos), ptr(var), None, None, ptr(gs.rowptr), ctypes.byref(t[0]), n, e, tw, nv,
+    check(L.msmp_edge_aggregate_tiled_f32(ptr(h), ptr(u), ptr(pos), ptr(var), None, None, None, ptr(gs.rowptr), ctypes.byref(t[0]), n, e, tw, nv,
                                           ptr(blob), ptr(folded), st), 'tiled folded')
+    # with the packed [u | pos | vars] rows the staging reads the same values: bit-identical
+    from msmp_pde_amd.layers import node_features
+    feat = node_features(u, pos, var)
+    assert feat.shape[1] == L.msmp_node_feature_stride(tw, nv)
+    assert torch.equal(feat[:, :tw], u) and torch.equal(feat[:, tw], pos) and torch.equal(feat[:, tw + 1:tw + 1 + nv], var) and not feat[:, tw + 1 + nv:].any()
     folded2 = torch.empty_like(folded)
-    check(L.msmp_edge_aggregate_tiled_f32(ptr(h), ptr(u), ptr(pos), ptr(var), None, None, ptr(gs.rowptr), ctypes.byref(t[0]), n, e, tw, nv,
-                                          ptr(blob), ptr(folded2), st), 'tiled folded')
+    check(L.msmp_edge_aggregate_tiled_f32(ptr(h), ptr(u), ptr(pos), ptr(var), ptr(feat), None, None, ptr(gs.rowptr), ctypes.byref(t[0]), n, e, tw, nv,
+                                          ptr(blob), ptr(folded2), st), 'tiled folded + feat')
     torch.cuda.synchronize()
     assert torch.equal(folded, folded2)
     scale = ref.abs().max().item()

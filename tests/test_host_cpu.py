@@ -44,12 +44,13 @@ def test_argument_errors_are_reported_not_thrown(mp):
     L = mp.lib()
     rc = L.msmp_scatter_mean_f32(None, None, 10, None, None)
     assert rc == -1 and b'null pointer' in L.msmp_last_error()
-    rc = L.msmp_mp_layer_f32(*([None] * 9), 1, 1, 1, 6, 100, 25, 2, None, None, 0, 1e-5, None, None, 0, None)
+    rc = L.msmp_mp_layer_f32(*([None] * 10), 1, 1, 1, 6, 100, 25, 2, None, None, 0, 1e-5, None, None, 0, None)
     assert rc == -1
     # every new entry point of this round validates its arguments the same way (no device work happens on these calls)
     assert L.msmp_node_tail_f32(*([None] * 5), 10, 1, 100, 2, None, None, 1, 1e-5, None, None) == -1
     assert L.msmp_build_tiles(None, None, 10, 20, 21, None, None, None, None, None) == -1
-    assert L.msmp_edge_aggregate_tiled_f32(*([None] * 8), 10, 20, 25, 2, None, None, None) == -1
+    assert L.msmp_edge_aggregate_tiled_f32(*([None] * 9), 10, 20, 25, 2, None, None, None) == -1
+    assert L.msmp_pack_node_features_f32(None, None, None, 10, 25, 2, None, None) == -1 and L.msmp_node_feature_stride(25, 2) == 32 and L.msmp_node_feature_stride(50, 3) == 64
     assert L.msmp_mlp2_swish_f32(None, 10, 28, None, None, None) == -1
     assert L.msmp_lem_encoder_nodes_f32(*([None] * 5), 10, 25, 2, 0, 1.0, None, 1, None, None) == -1
     assert L.msmp_decoder2d_f32(None, None, 10, 25, None, None, None, None, 0.016, None, None) == -1
