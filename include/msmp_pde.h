@@ -58,10 +58,6 @@ const char* msmp_last_error(void);
  *   "split"   1 (default): the GEMMs of the node / edge / LEM kernels run on the fp16 matrix pipe with a 2-way
  *             fp16 split of both operands (fp32-class accuracy); 0: the fp32-MFMA kernels.
  *   "edge_nb" 0 auto, 1 / 2 force the 128- / 256-edge tile of the factorised message kernel.
- *   "edge_occ" 2 (default) / 3 / 4: waves per SIMD the 128-edge factorised message kernel is compiled for.
- *   "edge_xcd" 1: workgroup b of the fused message kernels takes tile (b % 8) * ceil(tiles / 8) + b / 8, i.e. consecutive tiles on
- *             one XCD (measured: no effect, the tiles share too little); 0 (default): tile b.
- *   "edge_ws" 1: persistent weight-stationary message + mean kernel (max in-degree <= 32); 0 (default): streamed weights.
  *   "tile"    2 (default): with node tiles, project P / Q inside the message kernel; 1: msmp_node_project_f32 + tile kernel on the
  *             staged P / Q rows; 0: ignore the tiles (gather kernels).
  *   "tail"    1 (default): msmp_mp_layer_f32 uses msmp_node_tail_f32 for graphs of up to 128 nodes; 0: the piecewise kernels.

@@ -18,7 +18,6 @@ SOURCES = {  # file -> extra flags
     'lem_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
     'lem_train_kernel.hip': [],
     'train_kernels.hip': [],
-    'edge_ws_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
     'mlp2_kernel.hip': [],
     'decoder_kernel.hip': [],
     'graph_kernels.hip': ['-ffp-contract=off'],   # float64 distance compares must round like the host's

@@ -125,14 +125,7 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
     long tile_e0, tile_e1;     // CSR edge range of this workgroup
     int tile_n0 = 0, tile_n1 = 0;
     if (FUSE) {
-        // Workgroups are dealt round-robin over the 8 XCDs; with xcd_map each XCD gets a contiguous run of tiles, so the
-        // source rows that neighbouring tiles share (28 % of a tile's Q rows on the 1-D grids) meet in that XCD's L2.
-        unsigned tile = blockIdx.x;
-        if (a.xcd_map) {
-            const unsigned per = (gridDim.x + 7) / 8;
-            tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-            if ((long)tile * a.tile_nodes >= a.n_nodes) return;     // padding slots of the 8 x ceil(tiles / 8) enumeration
-        }
+        const unsigned tile = blockIdx.x;
         tile_n0 = tile * a.tile_nodes;
         tile_n1 = min((long)tile_n0 + a.tile_nodes, a.n_nodes);
         tile_e0 = a.rowptr[tile_n0];
@@ -392,18 +385,6 @@ struct EdgeArgs2 {
 __global__ __launch_bounds__(256, 2) void edge_mlp_pair_kernel_occ2(EdgeArgs2 a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
     edge_mlp_body<1, true, true, true>(a.head[blockIdx.y], lds);
-}
-
-template <int NB, bool FUSE, bool FACT, bool SPLIT = false>
-__global__ __launch_bounds__(256, 3) void edge_mlp_kernel_occ3(EdgeArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
-    edge_mlp_body<NB, FUSE, FACT, SPLIT>(a, lds);
-}
-
-template <int NB, bool FUSE, bool FACT, bool SPLIT = false>
-__global__ __launch_bounds__(256, 4) void edge_mlp_kernel_occ4(EdgeArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * H * LDW];
-    edge_mlp_body<NB, FUSE, FACT, SPLIT>(a, lds);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -993,7 +974,9 @@ struct TailArgs {
 struct HeadRows {
     f32x4 pf[4][4];
 };
-constexpr float TAIL_ACT_SCALE = 64.0f;
+constexpr float TAIL_ACT_SCALE = 64.0f;       // hidden units of the update net (Swish outputs)
+constexpr float TAIL_NODE_SCALE = 256.0f;     // node rows (h, aggregate, variables): saturating, see tile_kernels.hip
+__device__ __forceinline__ float tail_node_scaled(float x) { return __builtin_amdgcn_fmed3f(x * TAIL_NODE_SCALE, -65504.0f, 65504.0f); }
 __device__ __forceinline__ void head_row_load(const float* __restrict__ h, const float* __restrict__ agg, long nc, int hh, int ch,
                                               f32x4 (&dst)[4]) {
     const float* row32 = (ch < 4 ? h : agg) + (size_t)nc * H + 32 * (ch & 3);
@@ -1015,7 +998,7 @@ __device__ __forceinline__ void head_compute(HeadRows& st, const float* __restri
                                              int tid, int lane, int c, int hh, f32x16 (&yT)[4], MidHook mid_hook PROF_ARGS) {
     // ACT_SCALE: the node rows and the Swish output enter the split GEMMs multiplied by 2^6, so that the fp16 low halves of small
     // activations stay normal (see tile_kernels.hip); every factor is a power of two folded into an existing constant.
-    const float sc3 = scales[2] * TAIL_ACT_SCALE, inv3 = scales[6], sc4 = scales[3] * TAIL_ACT_SCALE;
+    const float sc3 = scales[2] * TAIL_NODE_SCALE, inv3 = scales[6] * (TAIL_ACT_SCALE / TAIL_NODE_SCALE), sc4 = scales[3] * TAIL_ACT_SCALE;
     WStage ws;
     wstage_load(ws, w3s, tid);
     float xv[8];
@@ -1031,14 +1014,15 @@ __device__ __forceinline__ void head_compute(HeadRows& st, const float* __restri
         half8 bhi[1][2], blo[1][2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const f32x4 v0 = st.pf[ch & 3][2 * s] * TAIL_ACT_SCALE, v1 = st.pf[ch & 3][2 * s + 1] * TAIL_ACT_SCALE;
-            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const f32x4 v0 = st.pf[ch & 3][2 * s], v1 = st.pf[ch & 3][2 * s + 1];
+            const float v[8] = {tail_node_scaled(v0[0]), tail_node_scaled(v0[1]), tail_node_scaled(v0[2]), tail_node_scaled(v0[3]),
+                                tail_node_scaled(v1[0]), tail_node_scaled(v1[1]), tail_node_scaled(v1[2]), tail_node_scaled(v1[3])};
             split8(v, bhi[0][s], blo[0][s]);
         }
         if (ch + 4 < 8) head_row_load(h, agg, nc, hh, ch + 4, st.pf[ch & 3]);
         if (ch == 5) {      // the variables and their slot fragments are consumed after the k loop: issued two chunks ahead
 #pragma unroll
-            for (int f = 0; f < 8; ++f) xv[f] = f < nv ? vars[(size_t)nc * nv + f] * TAIL_ACT_SCALE : 0.f;
+            for (int f = 0; f < 8; ++f) xv[f] = f < nv ? tail_node_scaled(vars[(size_t)nc * nv + f]) : 0.f;
             const half8* wv = reinterpret_cast<const half8*>(w3vh) + lane;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -1299,14 +1283,8 @@ extern "C" int msmp_node_project_f32(const float* h, const float* u, const float
     return check_launch("node_proj_kernel");
 }
 
-static int g_edge_occ = 2;     // waves per SIMD of the default message kernel (msmp_tune "edge_occ" 2 / 3 / 4).  With the row bounds of the
-                               // epilogue prefetched, 2 (256 registers, no spill) measures 4 % faster than 4 (128 registers, 5 spilled): 2.28 vs 2.37 ms
 static int g_edge_nb = 0;    // tuning override (msmp_tune): 0 = automatic, 1 / 2 = force the tile size of the factorised kernel
 
-extern int g_edge_ws_waves;
-static int g_edge_xcd = 0;   // XCD-contiguous tile order in the fused message kernels (msmp_tune "edge_xcd")
-static int g_edge_ws = 0;    // 1: persistent weight-stationary message + mean kernel (max in-degree <= 32; msmp_tune "edge_ws");
-                             // measured equal to the streamed-weight kernel (2.43 vs 2.41 ms per step), so the latter stays the default
 static int g_pair = 1;       // gated pair: both heads' projection / message kernels in one launch each: 0 never, 1 up to PAIR_MAX_NODES nodes, 2 always
 constexpr int64_t PAIR_MAX_NODES = 65536;     // measured (E2, ms per rollout step, per-head vs paired): 256 graphs 1.33 / 1.14, 512: 2.06 / 1.95, 1024: 3.63 / 3.65, 2048: 6.95 / 7.07
 static int g_tile = 2;       // node tiles (tile_kernels.hip): 2 fold the projections into the message kernel, 1 staged P / Q rows, 0 off
@@ -1323,11 +1301,7 @@ extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "tail")) { g_tail = value; return MSMP_OK; }
     if (key && !strcmp(key, "pair")) { g_pair = value; return MSMP_OK; }
     if (key && !strcmp(key, "tile")) { g_tile = value; return MSMP_OK; }
-    if (key && !strcmp(key, "edge_ws")) { g_edge_ws = value; return MSMP_OK; }
-    if (key && !strcmp(key, "edge_xcd")) { g_edge_xcd = value; return MSMP_OK; }
-    if (key && !strcmp(key, "edge_ws_waves")) { g_edge_ws_waves = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
-    if (key && !strcmp(key, "edge_occ")) { g_edge_occ = value; return MSMP_OK; }
     if (key && !strcmp(key, "lem")) { g_lem_split = value; return MSMP_OK; }
     if (key && !strcmp(key, "lem_nodes")) { g_lem_nodes = value; return MSMP_OK; }
     if (key && !strcmp(key, "split")) { g_split = value; g_lem_split = value ? 3 : 0; return MSMP_OK; }
@@ -1335,8 +1309,6 @@ extern "C" int msmp_tune(const char* key, int value) {
     return MSMP_ERR_ARG;
 }
 
-int msmp_launch_edge_ws(const float* P, const float* Q, const int32_t* rowptr, const int32_t* col, const int32_t* tgt, int64_t n_nodes,
-                        int max_in_degree, const float* w2t, const float* b2, const float* scales, float* agg, hipStream_t stream);
 static int edge_aggregate(const float* h, const float* u, const float* pos, const float* vars, const float* P, const float* Q,
                           const int32_t* rowptr, const int32_t* col, const int32_t* tgt, int64_t n_nodes, int64_t n_edges,
                           int max_in_degree, int tw, int nv, const float* packed, float* agg_out, msmp_stream_t stream,
@@ -1358,17 +1330,11 @@ static int edge_aggregate(const float* h, const float* u, const float* pos, cons
     const PackedLayout L = packed_layout(tw, nv);
     int tile_nodes = max_in_degree > 0 ? edges_per_tile / max_in_degree : edges_per_tile;
     if (tile_nodes > 256) tile_nodes = 256;      // keeps the per-tile node loop short when degrees are tiny
-    EdgeArgs a{h, u, pos, vars, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, g_edge_xcd, tw, nv, L.nc1,
+    EdgeArgs a{h, u, pos, vars, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, 0, tw, nv, L.nc1,
                packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, P, Q, nullptr, agg_out};
-    unsigned grid = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
-    if (g_edge_xcd) grid = (grid + 7) / 8 * 8;      // the XCD remap enumerates 8 x ceil(tiles / 8) slots; slots past the last tile exit
+    const unsigned grid = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
     timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
-    if (P && g_split && g_edge_ws && max_in_degree >= 1 && max_in_degree <= 32)
-        msmp_launch_edge_ws(P, Q, rowptr, col, tgt, n_nodes, max_in_degree, packed + L.w2t, packed + L.b2, packed + L.scales, agg_out,
-                            (hipStream_t)stream);
-    else if (P && edges_per_tile == 128 && g_split && g_edge_occ == 4) hipLaunchKernelGGL((edge_mlp_kernel_occ4<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else if (P && edges_per_tile == 128 && g_split && g_edge_occ == 3) hipLaunchKernelGGL((edge_mlp_kernel_occ3<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else if (P && edges_per_tile == 128 && g_split) hipLaunchKernelGGL((edge_mlp_kernel_occ2<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (P && edges_per_tile == 128 && g_split) hipLaunchKernelGGL((edge_mlp_kernel_occ2<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (P && edges_per_tile == 128) hipLaunchKernelGGL((edge_mlp_kernel<1, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (P) hipLaunchKernelGGL((edge_mlp_kernel<2, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((edge_mlp_kernel<2, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -1384,7 +1350,7 @@ int msmp_pair_project_aggregate(const float* h, const float* u, const float* pos
                                 int nv, const float* packed_a, const float* packed_b, float* p_a, float* q_a, float* p_b, float* q_b,
                                 float* agg_a, float* agg_b, msmp_stream_t stream) {
     if (!g_pair || (g_pair == 1 && n_nodes > PAIR_MAX_NODES)) return MSMP_ERR_UNSUPPORTED;
-    if (!g_split || g_edge_ws || g_edge_occ != 2 || g_edge_nb == 2 || g_edge_xcd) return MSMP_ERR_UNSUPPORTED;
+    if (!g_split || g_edge_nb == 2) return MSMP_ERR_UNSUPPORTED;
     if (n_edges <= 0 || max_in_degree <= 0 || max_in_degree > 128 || n_edges >= (1L << 31) || n_nodes >= (1L << 31)) return MSMP_ERR_UNSUPPORTED;
     const PackedLayout L = packed_layout(tw, nv);
     hipStream_t st = (hipStream_t)stream;

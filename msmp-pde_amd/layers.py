@@ -32,11 +32,38 @@ def _linear(i, o):
 
 
 class _Workspace(object):
-    """Grow-only scratch buffer per device, shared by all layers (the C-ABI never allocates)."""
+    """Grow-only scratch buffer per device, shared by all layers (the C-ABI never allocates).  `private(device)` is a context
+    in which the layers of the calling thread use buffers of their own instead (hipGraph capture: the captured launches must
+    point at memory nobody replaces; solvers._GraphedForward keeps those buffers alive as long as the graph)."""
     _bufs = {}
+    _private = None
+
+    class _Private(object):
+        def __init__(self, device):
+            self.device, self.buf = device, None
+
+        def __enter__(self):
+            self._outer, _Workspace._private = _Workspace._private, self
+            return self
+
+        def __exit__(self, *exc):
+            _Workspace._private = self._outer
+
+        def buffers(self):
+            return [self.buf]
+
+    @classmethod
+    def private(cls, device):
+        return cls._Private(device)
 
     @classmethod
     def get(cls, nbytes, device):
+        p = cls._private
+        if p is not None and p.device == device:
+            if p.buf is None or p.buf.numel() < nbytes:
+                assert not torch.cuda.is_current_stream_capturing() or p.buf is None, 'workspace grew during capture'
+                p.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            return p.buf
         buf = cls._bufs.get(device)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(nbytes, dtype=torch.uint8, device=device)

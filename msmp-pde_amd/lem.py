@@ -124,8 +124,10 @@ class _LEMTrainFunction(torch.autograd.Function):
 class LEM(nn.Module):
     """experiments/models_gnn.py:333-342: returns all_y[-1].
 
-    `forward` is the differentiable path: on the GPU the HIP training kernels (_LEMTrainFunction; TRAIN_KERNELS = False
-    selects the PyTorch restatement LEMcuda.forward instead, which is also what CPU tensors get).  `encode` /
+    `forward` is the differentiable path: the HIP training kernels (_LEMTrainFunction).  There is NO CPU path: host tensors
+    raise.  TRAIN_KERNELS = False is a validation aid only (scripts/train_soak.py, scripts/train_step_time.py): it routes GPU
+    tensors through the PyTorch-ROCm restatement `LEMcuda.forward`, which the tests also call directly in float64 as the
+    reference of the kernels.  `encode` /
     `encode_nodes` are the product path for inference: the fused HIP kernel (recurrence + lemoutput_mlp in one launch,
     states in registers)."""
     TRAIN_KERNELS = True
@@ -139,13 +141,13 @@ class LEM(nn.Module):
 
     def forward(self, inputs):
         """inputs [T, N, ninp] (the reference's layout) -> all_y[-1] [N, nhid]."""
-        if inputs.is_cuda and self.TRAIN_KERNELS and self.nhid == 128:
-            return self.forward_nodes(inputs.permute(1, 0, 2))
-        return self.rnn(inputs)
+        return self.forward_nodes(inputs.permute(1, 0, 2))
 
     def forward_nodes(self, xin):
         """Same with node-major step inputs xin [N, T, ninp] (the layout the kernels read)."""
-        if not (xin.is_cuda and self.TRAIN_KERNELS and self.nhid == 128):
+        if not xin.is_cuda or self.nhid != 128:
+            raise RuntimeError('LEM runs on the HIP kernels only (CUDA tensors, 128 hidden features); there is no CPU fallback')
+        if not self.TRAIN_KERNELS:
             return self.rnn(xin.permute(1, 0, 2).contiguous())
         r = self.rnn
         return _LEMTrainFunction.apply(self, xin, r.weights, r.weights_lin_z, r.bias, r.bias_lin_z)[0]

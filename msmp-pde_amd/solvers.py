@@ -43,6 +43,17 @@ def _decoder_autograd(x, conv1, conv2):
     return torch.einsum('nctk,ock->not', w2, conv2.weight) + conv2.bias[None, :, None]
 
 
+class _Conv1dNoMIOpen(nn.Conv1d):
+    """nn.Conv1d (same parameters and state_dict keys: `weight`, `bias`) whose forward is unfold + einsum.  Under autograd the
+    library path of these decoder shapes ([N, C, 128], kernel 16 / stride 3 and [N, 8, 38], kernel 14) reaches MIOpen's
+    implicit-GEMM backward-data kernel, which faulted on MI355X (igemm_bwd_gtcx35_nhwc_fp32, round 1); `model.output_mlp(x)`
+    called the reference's way therefore never dispatches a MIOpen convolution, forward or backward."""
+
+    def forward(self, x):
+        w = x.unfold(2, self.kernel_size[0], self.stride[0])                         # [N, Cin, L, k]
+        return torch.einsum('nilk,cik->ncl', w, self.weight) + self.bias[None, :, None]
+
+
 class _OutEdgeMean(torch.autograd.Function):
     """Mean of a per-edge tensor [E,128] over each node's OUT-edges (torch_scatter `scatter(..., edge_index[0], reduce='mean')`,
     models_gnn2D.py:607-608) in a fixed summation order: edges regrouped by source once per graph structure, then
@@ -122,8 +133,8 @@ class _SolverBase(nn.Module):
         if self.TWO_D:
             self.double_mlp = nn.Sequential(_lin(hidden_features, 2 * hidden_features), Swish(),
                                             nn.Unflatten(1, (2, hidden_features)))
-        self.output_mlp = nn.Sequential(nn.Conv1d(comps, 8, k1, stride=s1, dtype=torch.float32), Swish(),
-                                        nn.Conv1d(8, comps, k2, stride=1, dtype=torch.float32))
+        self.output_mlp = nn.Sequential(_Conv1dNoMIOpen(comps, 8, k1, stride=s1, dtype=torch.float32), Swish(),
+                                        _Conv1dNoMIOpen(8, comps, k2, stride=1, dtype=torch.float32))
 
     def __repr__(self):
         return 'GNN'     # every helper of the reference dispatches on this (train_helper.py:99,110,124,...)
@@ -264,6 +275,15 @@ class _SolverBase(nn.Module):
 
 
 class _GraphedForward:
+    """hipGraph of one forward.  The captured kernels hold RAW pointers, so everything they point at is owned or pinned here:
+    * the static input buffers (x, pos) and the output;
+    * a PRIVATE layer workspace (layers._Workspace.private): the shared grow-only workspace of the eager path is replaced, and
+      its old buffer freed, as soon as any later call needs a larger one;
+    * the packed weight blobs the capture read (`layer._packed`, the encoder blobs): they are replaced after an optimizer step,
+      load_state_dict or invalidate_packed_weights().  References keep their memory alive, and `__call__` compares what the
+      blobs' caches key on (optimizer epoch, parameter storages and versions) with the capture-time values: on a mismatch the
+      graph is re-captured, never replayed against stale weights."""
+
     def __init__(self, model, data):
         import copy
         assert not torch.is_grad_enabled(), 'capture() is for inference: wrap it in torch.no_grad()'
@@ -271,18 +291,39 @@ class _GraphedForward:
         self.data = copy.copy(data)                       # shallow: shares edge_index / batch / variables / cached structure
         self.data.x = data.x.clone()
         self.data.pos = data.pos.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                     # warm-up on a side stream: weight packing, workspaces, CSR build
-            for _ in range(2):
-                model(self.data)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = model(self.data)
+        self._capture()
+
+    def _weight_state(self):
+        """What the packed-weight caches key on: the global epoch (optimizer steps, invalidate_packed_weights) and every
+        parameter's storage and version (load_state_dict, in-place edits)."""
+        return (PARAM_EPOCH[0], tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
+
+    def _weight_blobs(self):
+        return [getattr(m, attr) for m in self.model.modules() for attr in ('_packed', '_embed_blob') if getattr(m, attr, None) is not None]
+
+    def _capture(self):
+        from .layers import _Workspace
+        model = self.model
+        self.graph = None
+        with _Workspace.private(self.data.x.device) as ws:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                 # warm-up on a side stream: weight packing, workspaces, CSR build
+                for _ in range(2):
+                    model(self.data)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.out = model(self.data)
+            self.graph = graph
+        self._ws = ws.buffers()                           # pinned: the captured launches point into them
+        self._blobs = self._weight_blobs()                # pinned
+        self._state = self._weight_state()
 
     def __call__(self, data):
+        if self._state != self._weight_state():           # the weights changed since the capture: the eager path would re-pack them
+            self._capture()
         self.data.x.copy_(data.x)
         self.data.pos.copy_(data.pos)
         self.graph.replay()

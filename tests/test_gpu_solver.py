@@ -220,6 +220,36 @@ def test_captured_rollout_step_is_bit_identical(mp, name, exp):
             del junk
 
 
+def test_captured_forward_survives_workspace_growth_and_weight_updates(mp):
+    """the hipGraph of Solver.capture() bakes raw pointers.  (1) A later, LARGER eager batch replaces the shared layer
+    workspace: the replay must still equal eager (the capture owns a private workspace).  (2) After an optimizer step the packed
+    weight blobs are replaced: the next call must use the NEW weights (re-capture), not replay stale ones."""
+    torch.manual_seed(12)
+    small = synthetic_case(mp, 'E2', bsz=3, seed=4)
+    big = synthetic_case(mp, 'E2', bsz=24, seed=5)
+    model = mp.MP_PDE_SolverLEMLinGated(small.pde, time_window=TW, eq_variables=small.eqv, hidden_layer=2).cuda().eval()
+    g_small, g_big = small.graph.to('cuda'), big.graph.to('cuda')
+    with torch.no_grad():
+        ref = model(g_small)
+        step = model.capture(g_small)
+        assert torch.equal(step(g_small), ref)
+        for _ in range(3):
+            model(g_big)                                   # grows (replaces) the shared workspace and churns the allocator
+            junk = [torch.randn(1 << 20, device='cuda') for _ in range(8)]
+            del junk
+        assert torch.equal(step(g_small), ref)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, fused=True)
+    model.train()
+    loss = ((model(g_small) - g_small.y.float()) ** 2).sum()
+    loss.backward()
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        ref2 = model(g_small)
+        assert not torch.equal(ref2, ref)
+        assert torch.equal(step(g_small), ref2)
+
+
 def test_fails_loudly_without_gpu_tensors(mp):
     case = synthetic_case(mp, 'E2', bsz=2, seed=1, device='cpu')
     model = mp.MP_PDE_Solver(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=1)

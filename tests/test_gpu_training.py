@@ -392,3 +392,30 @@ def test_lems_state_carry(mp, ninp, n, t_len):
         y_zero = ref.rnn(xs[2].double().permute(1, 0, 2).contiguous())
     assert (y_reset.double() - y_zero).abs().max().item() < 1e-5
     assert (y_reset - y.detach()).abs().max().item() > 1e-2
+
+
+@pytest.mark.parametrize('name,exp', [('MP-PDE', 'E2'), ('Gated2D', 'MSWG3')])
+def test_output_mlp_called_the_reference_way_never_reaches_miopen(mp, name, exp):
+    """`model.output_mlp(h[:, None])` under autograd (what reference-style code does, models_gnn.py:278) must
+    not dispatch MIOpen's convolution (its backward-data kernel faulted on MI355X).  The decoder modules are nn.Conv1d subclasses
+    with an unfold + einsum forward: same state_dict keys, same values as F.conv1d, gradients equal to float64 autograd, and the
+    profiler sees no convolution op."""
+    import torch.nn.functional as F
+    torch.manual_seed(1)
+    case = synthetic_case(mp, exp, bsz=2, seed=3)
+    model = mp.MODEL_NAMES[name](case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=1).cuda()
+    assert set(k for k in model.state_dict() if k.startswith('output_mlp')) == {'output_mlp.0.weight', 'output_mlp.0.bias', 'output_mlp.2.weight', 'output_mlp.2.bias'}
+    comps = 2 if '2D' in name else 1
+    x = torch.randn(50, comps, 128, device='cuda', requires_grad=True)
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+        out = model.output_mlp(x)
+        out.square().sum().backward()
+    ops = {e.key for e in prof.key_averages()}
+    assert not any('convolution' in o or 'miopen' in o.lower() for o in ops), sorted(o for o in ops if 'conv' in o.lower())
+    c1, c2 = model.output_mlp[0], model.output_mlp[2]
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    mid = F.conv1d(x64, c1.weight.detach().double().cpu(), c1.bias.detach().double().cpu(), stride=c1.stride[0])
+    ref = F.conv1d(mid * torch.sigmoid(mid), c2.weight.detach().double().cpu(), c2.bias.detach().double().cpu())
+    ref.square().sum().backward()
+    assert (out.detach().double().cpu() - ref.detach()).abs().max().item() < 1e-5
+    assert (x.grad.double().cpu() - x64.grad).abs().max().item() < 1e-4 * x64.grad.abs().max().item()

@@ -59,8 +59,8 @@ def test_argument_errors_are_reported_not_thrown(mp):
     assert L.msmp_mp_layer_bwd_f32(*([None] * 9), 10, 20, 1, 25, 2, None, None, 1, 1e-5, None, None, None, None, 0, None) == -1
     assert L.msmp_mp_layer_bwd_workspace_bytes(0, 5, 25, 2, 1) == 0 and L.msmp_mp_layer_bwd_workspace_bytes(100, 588, 25, 2, 1) > 0
     # knobs: known keys are accepted, unknown ones rejected with a message
-    for key in (b'split', b'edge_nb', b'edge_occ', b'edge_ws', b'edge_xcd', b'tail', b'pair', b'lem', b'lem_nodes', b'tile'):
-        assert L.msmp_tune(key, {b'split': 1, b'edge_occ': 2, b'tail': 1, b'lem': 3, b'lem_nodes': 1, b'pair': 1, b'tile': 2}.get(key, 0)) == 0, key
+    for key in (b'split', b'edge_nb', b'tail', b'pair', b'lem', b'lem_nodes', b'tile'):
+        assert L.msmp_tune(key, {b'split': 1, b'tail': 1, b'lem': 3, b'lem_nodes': 1, b'pair': 1, b'tile': 2}.get(key, 0)) == 0, key
     assert L.msmp_tune(b'no_such_knob', 1) != 0 and b'unknown key' in L.msmp_last_error()
 
 
@@ -137,13 +137,16 @@ def test_no_cpu_fallback(mp):
 
 
 def test_lem_encoder_matches_oracle_cell(mp):
-    """The PyTorch LEM restatement and the oracle's cell agree (both follow the published cell; unpinned)."""
+    """The PyTorch LEM restatement (LEMcuda.forward: the kernels' float64 reference in the GPU tests) and the oracle's cell agree
+    (both follow the published cell; unpinned); the module itself has no CPU path: host tensors raise."""
     from oracle import msmp_oracle as O
     torch.manual_seed(0)
     lem = mp.LEM(4, 128)
     x = torch.randn(25, 50, 4)
+    with pytest.raises(RuntimeError):
+        lem(x)
     with torch.no_grad():
-        y = lem(x).double().numpy()
+        y = lem.rnn(x).double().numpy()
     sd = {k: v.numpy().astype(np.float64) for k, v in lem.state_dict().items()}
     ref = O.lem_forward(x.numpy().astype(np.float64), sd['rnn.weights'], sd['rnn.weights_lin_z'], sd['rnn.bias'],
                         sd['rnn.bias_lin_z'], 1.0)
