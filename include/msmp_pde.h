@@ -324,15 +324,26 @@ int msmp_lem_train_bwd_f32(const float* grad_y, const float* saved, const float*
  * arrays of 8 device pointers in the order message_net_1.0.weight, .bias, message_net_2.0.weight, .bias, update_net_1.0.weight,
  * .bias, update_net_2.0.weight, .bias, in the reference's [out, in] layouts (NOT the packed blobs); gate arrays NULL for a
  * single layer.  u, pos, vars carry no gradient.  GEMMs with edge- / node-sized outputs run on rocBLAS (looked up in the
- * process at run time: MSMP_ERR_UNSUPPORTED if librocblas cannot be loaded); dh's source-side scatter uses atomics.
+ * process at run time: MSMP_ERR_UNSUPPORTED if librocblas cannot be loaded).  src_rowptr [N+1] / src_perm [E] (both or
+ * neither): the CSR edge ids regrouped by SOURCE node, ascending inside a source; with them dh's source-side scatter runs in
+ * that fixed order (bitwise reproducible gradients), without them it uses float atomics.  tw + 1 + nv <= 64.
  * Workspace: msmp_mp_layer_bwd_workspace_bytes (0 for invalid sizes). */
 size_t msmp_mp_layer_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int tw, int nv, int gated);
 int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, const float* u, const float* pos, const float* vars,
-                          const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const int32_t* graph_ptr,
+                          const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const int32_t* src_rowptr,
+                          const int32_t* src_perm, const int32_t* graph_ptr,
                           int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int tw, int nv,
                           const float* const* params_main, const float* const* params_gate, int mode, float eps,
                           float* dh_out, float* const* grads_main, float* const* grads_gate, void* workspace,
                           size_t workspace_bytes, msmp_stream_t stream);
+
+/* Fused AdamW step over all parameter tensors (experiments/train.py:410: optim.AdamW(model.parameters(), lr=args.lr); PyTorch
+ * defaults betas (0.9, 0.999), eps 1e-8, weight_decay 1e-2): arrays of n_tensors device pointers (parameter, gradient, first and
+ * second moment: fp32, contiguous) and element counts (host array); `step` = 1, 2, ... (bias correction).  One launch per 48
+ * tensors.  Same update rule and order of operations as torch.optim.AdamW. */
+int msmp_adamw_f32(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int64_t step, msmp_stream_t stream);
 
 /* The per-edge input of message_net_1 (models_gnn.py:69-75): out[e] = cat(h[i], h[j], u[i]-u[j], pos[i]-pos[j], vars[i]),
  * i = tgt[e], j = col[e]; out [E, ld] with ld >= 256 + tw + 1 + nv a multiple of 4 (columns past the concat are not written). */

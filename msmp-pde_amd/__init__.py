@@ -8,6 +8,7 @@ from .pde import CE, WE, AD                                                   # 
 from .graph import Data, GraphCreator, GraphStructure, structure_of, radius_graph, knn_graph   # noqa: F401
 from .layers import Swish, GNN_Layer, GNN_LayerLin, mp_layer                  # noqa: F401
 from .lem import LEM, LEMS                                                          # noqa: F401
+from . import optim                                                                 # noqa: F401  (optim.AdamW: fused HIP step)
 from .solvers import (MP_PDE_Solver, MP_PDE_SolverGated, MP_PDE_SolverLEMLinGated, MP_PDE_Solver2D,   # noqa: F401
                       MP_PDE_Solver2DGated, MP_PDE_Solver2DLEMLinGated, MP_PDE_SolverLEMLin, MP_PDE_Solver2DLEMLin,
                       MP_PDE_Solver2DLEMLinG2, MSSMP_PDE_Solver, MSSMP_PDE_Solver_sub,

@@ -35,8 +35,10 @@ def layer_backward_native(gout, h, u, pos, variables, gs, params, mode_lin, gate
     if ws is None or ws.numel() < need:
         ws = _bwd_ws[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
     arr = lambda ts: (ctypes.c_void_p * 8)(*[t.data_ptr() for t in ts])
+    # edges regrouped by source: the source-side scatter of dL/dh runs in a fixed order (an edgeless batch has nothing to scatter)
+    perm32, src_rowptr = gs.by_source32() if e else (None, None)
     check(L.msmp_mp_layer_bwd_f32(ptr(g), ptr(h), ptr(u), ptr(pos), ptr(variables), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt),
-                                  ptr(gs.graph_ptr), n, e, gs.n_graphs, tw, nv, arr(ps[:8]), arr(ps[8:]) if gated else None,
+                                  ptr(src_rowptr), ptr(perm32), ptr(gs.graph_ptr), n, e, gs.n_graphs, tw, nv, arr(ps[:8]), arr(ps[8:]) if gated else None,
                                   1 if (mode_lin or gated) else 0, eps, ptr(dh), arr(grads[:8]), arr(grads[8:]) if gated else None,
                                   ptr(ws), ws.numel(), current_stream()), 'msmp_mp_layer_bwd_f32')
     return dh, grads

@@ -475,6 +475,22 @@ __global__ __launch_bounds__(256) void scatter_source_kernel(float* __restrict__
     }
 }
 
+// the same in a FIXED order: the edges regrouped by source (src_rowptr [N+1], src_perm [E] = CSR edge ids, ascending inside a
+// source), thread = (node, channel group): run-to-run bitwise reproducible gradients
+__global__ __launch_bounds__(256) void scatter_source_sorted_kernel(float* __restrict__ dh, const float* __restrict__ d, int ld,
+                                                                    const int* __restrict__ src_rowptr, const int* __restrict__ src_perm,
+                                                                    long n_nodes) {
+    const long total = n_nodes * (H / 4);
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const long n = p >> 5;
+        const int cg = (int)(p & 31);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = src_rowptr[n]; k < src_rowptr[n + 1]; ++k)
+            s += *reinterpret_cast<const f32x4*>(d + (size_t)src_perm[k] * ld + H + 4 * cg);
+        reinterpret_cast<f32x4*>(dh)[p] += s;
+    }
+}
+
 static unsigned grid_for(long work_items) {
     const long b = (work_items + 255) / 256;
     return (unsigned)(b < 1 ? 1 : b > 32768 ? 32768 : b);
@@ -482,7 +498,7 @@ static unsigned grid_for(long work_items) {
 
 struct BwdCtx {
     const float *h, *u, *pos, *vars;
-    const int32_t *rowptr, *col, *tgt, *graph_ptr;
+    const int32_t *rowptr, *col, *tgt, *graph_ptr, *src_rowptr, *src_perm;
     long n, e, g;
     int tw, nv, kmsg, kupd, ld_e, ld_n;
     hipStream_t st;
@@ -552,7 +568,11 @@ static int head_backward(const BwdCtx& c, Blas& bl, const float* const* p, HeadB
         hipLaunchKernelGGL(dsilu_mul_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.x1, b.a1, b.x1, e * 32);             // d a1
         BLAS_OK(gemm_nn(bl, (int)e, 2 * H, H, b.x1, H, p[0], c.kmsg, b.dcat_e, 2 * H), "d message_net_1");                      // [d x_i | d x_j]
         hipLaunchKernelGGL(scatter_target_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.rowptr, n);
-        hipLaunchKernelGGL(scatter_source_kernel, dim3(grid_for(e * H)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.col, e);
+        if (c.src_rowptr)
+            hipLaunchKernelGGL(scatter_source_sorted_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.src_rowptr,
+                               c.src_perm, n);
+        else
+            hipLaunchKernelGGL(scatter_source_kernel, dim3(grid_for(e * H)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.col, e);
         jobs.add(b.x1, b.cat_e, e, c.ld_e, c.kmsg, grads[0], grads[1]);
         jobs.add(b.x2, b.m1, e, H, H, grads[2], grads[3]);
     } else {          // no edges: the message layers get zero gradients
@@ -588,7 +608,8 @@ extern "C" size_t msmp_mp_layer_bwd_workspace_bytes(int64_t n_nodes, int64_t n_e
 }
 
 extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, const float* u, const float* pos, const float* vars,
-                                     const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const int32_t* graph_ptr,
+                                     const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const int32_t* src_rowptr,
+                                     const int32_t* src_perm, const int32_t* graph_ptr,
                                      int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int tw, int nv,
                                      const float* const* params_main, const float* const* params_gate, int mode, float eps,
                                      float* dh_out, float* const* grads_main, float* const* grads_gate, void* workspace,
@@ -596,6 +617,7 @@ extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, cons
     MSMP_REQUIRE(grad_out && h && u && pos && vars && rowptr && col && tgt && graph_ptr && params_main && dh_out && grads_main && workspace,
                  MSMP_ERR_ARG, "msmp_mp_layer_bwd_f32: null pointer");
     MSMP_REQUIRE((params_gate != nullptr) == (grads_gate != nullptr), MSMP_ERR_ARG, "msmp_mp_layer_bwd_f32: give both gate arguments or none");
+    MSMP_REQUIRE((src_rowptr != nullptr) == (src_perm != nullptr), MSMP_ERR_ARG, "msmp_mp_layer_bwd_f32: give both of src_rowptr, src_perm or neither");
     const bool gated = params_gate != nullptr;
     MSMP_REQUIRE(mode == MSMP_LAYER_LIN || mode == MSMP_LAYER_RESIDUAL_SWISH, MSMP_ERR_ARG, "msmp_mp_layer_bwd_f32: bad mode %d", mode);
     MSMP_REQUIRE(!gated || mode == MSMP_LAYER_LIN, MSMP_ERR_ARG, "msmp_mp_layer_bwd_f32: the gated pair uses GNN_LayerLin layers");
@@ -612,7 +634,7 @@ extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, cons
     hipStream_t st = (hipStream_t)stream;
     MSMP_REQUIRE(bl.set_stream(bl.handle, st) == rocblas_status_success, MSMP_ERR_HIP, "msmp_mp_layer_bwd_f32: rocblas_set_stream failed");
 
-    BwdCtx c{h, u, pos, vars, rowptr, col, tgt, graph_ptr, (long)n_nodes, (long)n_edges, (long)n_graphs, tw, nv,
+    BwdCtx c{h, u, pos, vars, rowptr, col, tgt, graph_ptr, src_rowptr, src_perm, (long)n_nodes, (long)n_edges, (long)n_graphs, tw, nv,
              2 * H + tw + 1 + nv, 2 * H + nv, 0, 0, st};
     c.ld_e = (c.kmsg + 3) / 4 * 4;
     c.ld_n = (c.kupd + 3) / 4 * 4;
@@ -643,4 +665,75 @@ extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, cons
         RC(head_backward(c, bl, params_main, bm, dh_out, grads_main, jobs));
     }
     return launch_grad_weights(jobs.n, jobs.a, jobs.b, jobs.rows, jobs.lda, jobs.ldb, jobs.k2, jobs.out_w, jobs.out_b, gw_ws, gw_floats, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Fused AdamW (experiments/train.py:410: optim.AdamW(model.parameters(), lr)): every parameter tensor of the model in one or two
+// launches.  A launch carries up to ADAMW_MAX_TENSORS tensor descriptors in its kernel arguments; block b works on chunk
+// (b - first_block[t]) of tensor t.  Decoupled weight decay, bias-corrected moments, the same order of operations as
+// torch.optim.AdamW (p *= 1 - lr wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;  p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)).
+// ------------------------------------------------------------------------------------------------------------------------
+namespace msmp {
+constexpr int ADAMW_MAX_TENSORS = 48;
+constexpr int ADAMW_CHUNK = 4096;           // elements per block (256 threads x 4 x 4)
+struct AdamWArgs {
+    float* p[ADAMW_MAX_TENSORS];
+    const float* g[ADAMW_MAX_TENSORS];
+    float* m[ADAMW_MAX_TENSORS];
+    float* v[ADAMW_MAX_TENSORS];
+    int numel[ADAMW_MAX_TENSORS];
+    int first_block[ADAMW_MAX_TENSORS + 1];
+    int n;
+    float lr, beta1, beta2, eps, decay, bc1_inv, bc2_rsqrt;      // decay = 1 - lr wd;  bc1_inv = 1 / (1 - b1^t);  bc2_rsqrt = 1 / sqrt(1 - b2^t)
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamWArgs a) {
+    int t = 0;
+    while (t + 1 < a.n && (int)blockIdx.x >= a.first_block[t + 1]) ++t;
+    const int base = ((int)blockIdx.x - a.first_block[t]) * ADAMW_CHUNK;
+    const int n = a.numel[t];
+    float* __restrict__ p = a.p[t];
+    const float* __restrict__ g = a.g[t];
+    float* __restrict__ m = a.m[t];
+    float* __restrict__ v = a.v[t];
+    const float step = a.lr * a.bc1_inv;
+#pragma unroll
+    for (int k = 0; k < ADAMW_CHUNK / 256; ++k) {
+        const int i = base + k * 256 + threadIdx.x;
+        if (i < n) {
+            const float gi = g[i];
+            const float mi = a.beta1 * m[i] + (1.0f - a.beta1) * gi;
+            const float vi = a.beta2 * v[i] + (1.0f - a.beta2) * gi * gi;
+            m[i] = mi;
+            v[i] = vi;
+            p[i] = p[i] * a.decay - step * (mi / (sqrtf(vi) * a.bc2_rsqrt + a.eps));
+        }
+    }
+}
+}  // namespace msmp
+
+extern "C" int msmp_adamw_f32(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                              float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int64_t step, msmp_stream_t stream) {
+    MSMP_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (params && grads && exp_avg && exp_avg_sq && numel)), MSMP_ERR_ARG, "msmp_adamw_f32: null pointer");
+    MSMP_REQUIRE(step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, MSMP_ERR_ARG, "msmp_adamw_f32: bad hyper-parameters");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    for (int t0 = 0; t0 < n_tensors; t0 += ADAMW_MAX_TENSORS) {
+        AdamWArgs a;
+        a.n = n_tensors - t0 < ADAMW_MAX_TENSORS ? n_tensors - t0 : ADAMW_MAX_TENSORS;
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            MSMP_REQUIRE(params[t0 + i] && grads[t0 + i] && exp_avg[t0 + i] && exp_avg_sq[t0 + i] && numel[t0 + i] >= 0 && numel[t0 + i] < (1L << 31),
+                         MSMP_ERR_ARG, "msmp_adamw_f32: bad tensor %d", t0 + i);
+            a.p[i] = params[t0 + i]; a.g[i] = grads[t0 + i]; a.m[i] = exp_avg[t0 + i]; a.v[i] = exp_avg_sq[t0 + i];
+            a.numel[i] = (int)numel[t0 + i];
+            a.first_block[i] = blocks;
+            blocks += (int)((numel[t0 + i] + ADAMW_CHUNK - 1) / ADAMW_CHUNK);
+        }
+        a.first_block[a.n] = blocks;
+        a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.decay = 1.0f - lr * weight_decay;
+        a.bc1_inv = (float)(1.0 / bc1); a.bc2_rsqrt = (float)(1.0 / sqrt(bc2));
+        if (blocks) hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return check_launch("adamw_kernel");
 }

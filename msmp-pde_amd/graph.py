@@ -126,6 +126,13 @@ class GraphStructure(object):
             self._by_source = (perm, rowptr)
         return self._by_source
 
+    def by_source32(self):
+        """(perm int32, rowptr int32) of by_source() for the kernels (msmp_mp_layer_bwd_f32's deterministic scatter); made once."""
+        if getattr(self, '_by_source32', None) is None:
+            perm, rowptr = self.by_source()
+            self._by_source32 = (perm.to(torch.int32).contiguous(), rowptr)
+        return self._by_source32
+
     def matches(self, edge_index, batch):
         return self._key == (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
                              batch.data_ptr(), batch._version)

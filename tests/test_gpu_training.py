@@ -299,6 +299,9 @@ def test_layer_backward_entry_vs_float64_autograd(mp, form, n_edges):
                 r(128, k3) / k3 ** 0.5, r(128) * 0.1, r(128, 128) / 128 ** 0.5, r(128) * 0.1]
     ps = params() + (params() if form == 'gated' else [])
     dh, grads = A.layer_backward_native(gout, h, u, pos, var, gs, ps, form != 'residual', form == 'gated', eps)
+    dh2, grads2 = A.layer_backward_native(gout, h, u, pos, var, gs, ps, form != 'residual', form == 'gated', eps)
+    # no atomics anywhere (the source-side scatter walks the edges regrouped by source): bitwise reproducible
+    assert torch.equal(dh, dh2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
     h64 = h.double().requires_grad_(True)
     p64 = [q.double().requires_grad_(True) for q in ps]
     s64, d64 = gs.col_long, gs.tgt_long
@@ -419,3 +422,32 @@ def test_output_mlp_called_the_reference_way_never_reaches_miopen(mp, name, exp)
     ref.square().sum().backward()
     assert (out.detach().double().cpu() - ref.detach()).abs().max().item() < 1e-5
     assert (x.grad.double().cpu() - x64.grad).abs().max().item() < 1e-4 * x64.grad.abs().max().item()
+
+
+def test_fused_adamw_matches_torch(mp):
+    """msmp_pde_amd.optim.AdamW (one HIP launch per 48 tensors) against torch.optim.AdamW over several steps of a real model
+    (108 tensors of very different sizes, incl. 1-element and odd-sized ones), with a learning-rate change in between (MultiStepLR,
+    train.py:411); the packed-weight caches are invalidated by the step like with any optimizer."""
+    from msmp_pde_amd import _lib
+    torch.manual_seed(7)
+    case = synthetic_case(mp, 'E2', bsz=2, seed=3)
+    a = mp.MP_PDE_SolverLEMLinGated(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=2).cuda()
+    b = mp.MP_PDE_SolverLEMLinGated(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=2).cuda()
+    b.load_state_dict(a.state_dict())
+    oa = mp.optim.AdamW(a.parameters(), lr=1e-3)
+    ob = torch.optim.AdamW(b.parameters(), lr=1e-3)
+    sa = torch.optim.lr_scheduler.MultiStepLR(oa, milestones=[2], gamma=0.4)
+    sb = torch.optim.lr_scheduler.MultiStepLR(ob, milestones=[2], gamma=0.4)
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    for it in range(4):
+        epoch0 = _lib.PARAM_EPOCH[0]
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            g = torch.randn(pa.shape, device='cuda', generator=gen) * (0.1 + it)
+            pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step(); ob.step(); sa.step(); sb.step()
+        assert _lib.PARAM_EPOCH[0] > epoch0
+        for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
+            err = (pa - pb).abs().max().item()
+            assert err <= 2e-7 * max(1.0, pb.abs().max().item()) + 1e-9, (it, name, err)
+    st = oa.state_dict()
+    assert set(st['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}

@@ -52,11 +52,12 @@ def test_argument_errors_are_reported_not_thrown(mp):
     assert L.msmp_edge_aggregate_tiled_f32(*([None] * 9), 10, 20, 25, 2, None, None, None) == -1
     assert L.msmp_pack_node_features_f32(None, None, None, 10, 25, 2, None, None) == -1 and L.msmp_node_feature_stride(25, 2) == 32 and L.msmp_node_feature_stride(50, 3) == 64
     assert L.msmp_mlp2_swish_f32(None, 10, 28, None, None, None) == -1
+    assert L.msmp_adamw_f32(3, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, None) == -1
     assert L.msmp_lem_encoder_nodes_f32(*([None] * 5), 10, 25, 2, 0, 1.0, None, 1, None, None) == -1
     assert L.msmp_decoder2d_f32(None, None, 10, 25, None, None, None, None, 0.016, None, None) == -1
     assert L.msmp_packed_mlp2_floats(28) == 32 + 256 + (1 + 4) * 4096 and L.msmp_packed_mlp2_floats(129) == -1
     assert L.msmp_mlp2_input_stride(28) == 32 and L.msmp_mlp2_input_stride(59) == 64
-    assert L.msmp_mp_layer_bwd_f32(*([None] * 9), 10, 20, 1, 25, 2, None, None, 1, 1e-5, None, None, None, None, 0, None) == -1
+    assert L.msmp_mp_layer_bwd_f32(*([None] * 11), 10, 20, 1, 25, 2, None, None, 1, 1e-5, None, None, None, None, 0, None) == -1
     assert L.msmp_mp_layer_bwd_workspace_bytes(0, 5, 25, 2, 1) == 0 and L.msmp_mp_layer_bwd_workspace_bytes(100, 588, 25, 2, 1) > 0
     # knobs: known keys are accepted, unknown ones rejected with a message
     for key in (b'split', b'edge_nb', b'tail', b'pair', b'lem', b'lem_nodes', b'tile'):
