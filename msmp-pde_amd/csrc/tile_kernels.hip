@@ -14,6 +14,8 @@
 // of message_net_2 (fp16-split MFMA, weights streamed through LDS), Swish, per-target mean in CSR order through LDS.
 #include "mfma_tiles.h"
 
+#define TILE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+
 namespace msmp {
 
 // Phase profile (build with MSMP_PROF=tile in the environment of build.py; scripts/prof_tile.py reads it): cycle sums of wave 0 of
@@ -434,19 +436,19 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
             ahi[g] = w[(g * 2 + 0) * 64];
             alo[g] = w[(g * 2 + 1) * 64];
         }
-        __builtin_amdgcn_sched_barrier(0);
+        TILE_SCHED_BARRIER();
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int s = g >> 2, T = g & 3;
             y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[g], bhi[par][s], y[T], 0, 0, 0);
             y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[g], blo[par][s], y[T], 0, 0, 0);
             y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[g], bhi[par][s], y[T], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            TILE_SCHED_BARRIER();
             if (t < 3) {
                 act_slice(g);
                 if (g == 3) split_step(par ^ 1, 0);
                 if (g == 7) split_step(par ^ 1, 1);
-                __builtin_amdgcn_sched_barrier(0);
+                TILE_SCHED_BARRIER();
             }
         }
         if (t < 2) gather_tile(t + 2);          // P / Q pieces of the chunk after next: consumed in the next region
