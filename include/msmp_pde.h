@@ -177,6 +177,14 @@ int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes,
  * touch HBM.  feat (may be NULL): the packed [u | pos | vars] rows of msmp_pack_node_features_f32; they are the same for every
  * layer of a forward, so packing them once saves each layer's tile staging the scalar loads of those columns. */
 int msmp_node_feature_stride(int tw, int nv);
+/* Feature preparation of Solver.forward (experiments/models_gnn.py:1325-1352; models_gnn2D.py:104-116) in one launch: x [N,tw] and
+ * pos [N,2] = (t, x) in float32 or float64 (*_f64 flags), n_cols per-node parameter columns [N] (`cols`, `col_f64`, host arrays)
+ * each divided by col_div (1 for the boundary-condition flags) ->  u = float(x), pos_x = float(pos[:,1] / L),
+ * pos_t = float(pos[:,0] / tmax), vars [N, 1 + n_cols] = [pos_t | cols / div], and, if feat_out != NULL, the packed rows of
+ * msmp_pack_node_features_f32.  Divisions are evaluated in the input's dtype, like the tensor expressions they replace. */
+int msmp_prepare_nodes(const void* x, int x_f64, const void* pos, int pos_f64, int64_t n_nodes, int tw, double L, double tmax,
+                       int n_cols, const void* const* cols, const int* col_f64, const double* col_div, float* u_out,
+                       float* pos_x_out, float* pos_t_out, float* vars_out, float* feat_out, msmp_stream_t stream);
 int msmp_pack_node_features_f32(const float* u, const float* pos, const float* vars, int64_t n_nodes, int tw, int nv,
                                 float* feat_out, msmp_stream_t stream);
 int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, const float* pos, const float* vars, const float* feat,

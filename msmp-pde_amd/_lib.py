@@ -44,6 +44,8 @@ SIGNATURES = {
     'msmp_edge_aggregate_projected_f32': (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'msmp_build_tiles': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'msmp_node_feature_stride': (c_int, [c_int, c_int]),
+    'msmp_prepare_nodes': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'msmp_pack_node_features_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     'msmp_edge_aggregate_tiled_f32': (c_int, [c_void_p] * 8 + [ctypes.POINTER(MsmpTiles), c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'msmp_mp_layer_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int, c_int]),

@@ -132,6 +132,54 @@ __global__ __launch_bounds__(256) void pack_features_kernel(const float* __restr
     out[i] = v;
 }
 
+// Feature preparation of a forward in ONE launch (experiments/models_gnn.py:1325-1352, models_gnn2D.py:104-116): from the graph's
+// x [N,Tw], pos [N,2] = (t, x) and the per-node parameter columns it writes u = float(x), pos_x = float(pos[:,1] / L),
+// pos_t = float(pos[:,0] / tmax), variables = float([pos_t | col_k / div_k]) and (optionally) the packed feature rows above.
+// Divisions are done in the INPUT's dtype (float64 graphs: float64 division, then rounded to float32), exactly what the
+// PyTorch expressions they replace did (~20 small launches per forward before).
+struct PrepArgs {
+    const void* x;
+    const void* pos;
+    const void* col[MSMP_MAX_VARS];
+    double col_div[MSMP_MAX_VARS];
+    int col_f64[MSMP_MAX_VARS];
+    int x_f64, pos_f64, n_cols;
+    double L, tmax;
+    long n;
+    int tw, stride;            // stride = 32 * tail chunks >= tw + 1 + (1 + n_cols)
+    float *u, *pos_x, *pos_t, *vars, *feat;
+};
+__device__ __forceinline__ float prep_load(const void* p, int f64, long i) {
+    return f64 ? (float)reinterpret_cast<const double*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ float prep_div(const void* p, int f64, long i, double d) {
+    return f64 ? (float)(reinterpret_cast<const double*>(p)[i] / d) : reinterpret_cast<const float*>(p)[i] / (float)d;
+}
+__global__ __launch_bounds__(256) void prepare_nodes_kernel(PrepArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n * a.stride) return;
+    const long node = i / a.stride;
+    const int k = (int)(i - node * a.stride);
+    const int nv = 1 + a.n_cols;
+    float v = 0.f;
+    if (k < a.tw) {
+        v = prep_load(a.x, a.x_f64, node * a.tw + k);
+        a.u[node * a.tw + k] = v;
+    } else if (k == a.tw) {
+        v = prep_div(a.pos, a.pos_f64, 2 * node + 1, a.L);
+        a.pos_x[node] = v;
+    } else if (k == a.tw + 1) {
+        v = prep_div(a.pos, a.pos_f64, 2 * node, a.tmax);
+        a.pos_t[node] = v;
+        a.vars[node * nv] = v;
+    } else if (k <= a.tw + nv) {
+        const int c = k - a.tw - 2;
+        v = prep_div(a.col[c], a.col_f64[c], node, a.col_div[c]);
+        a.vars[node * nv + 1 + c] = v;
+    }
+    if (a.feat) a.feat[i] = v;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 struct TileArgs {
     const float* h;        // FOLD
@@ -593,6 +641,26 @@ extern "C" int msmp_pack_node_features_f32(const float* u, const float* pos, con
     hipLaunchKernelGGL(pack_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, pos, vars,
                        (long)n_nodes, tw, nv, stride, feat_out);
     return check_launch("pack_features_kernel");
+}
+
+extern "C" int msmp_prepare_nodes(const void* x, int x_f64, const void* pos, int pos_f64, int64_t n_nodes, int tw, double L, double tmax,
+                                  int n_cols, const void* const* cols, const int* col_f64, const double* col_div, float* u_out,
+                                  float* pos_x_out, float* pos_t_out, float* vars_out, float* feat_out, msmp_stream_t stream) {
+    MSMP_REQUIRE(x && pos && u_out && pos_x_out && pos_t_out && vars_out && (n_cols == 0 || (cols && col_f64 && col_div)), MSMP_ERR_ARG,
+                 "msmp_prepare_nodes: null pointer");
+    MSMP_REQUIRE(n_nodes > 0 && tw > 0 && n_cols >= 0 && n_cols < MSMP_MAX_VARS, MSMP_ERR_ARG, "msmp_prepare_nodes: bad sizes");
+    const int stride = msmp_node_feature_stride(tw, 1 + n_cols);
+    MSMP_REQUIRE(stride > 0 && stride <= 64 + 32, MSMP_ERR_ARG, "msmp_prepare_nodes: bad sizes");
+    PrepArgs a{};
+    a.x = x; a.pos = pos; a.x_f64 = x_f64; a.pos_f64 = pos_f64; a.n_cols = n_cols; a.L = L; a.tmax = tmax; a.n = (long)n_nodes; a.tw = tw;
+    a.stride = stride; a.u = u_out; a.pos_x = pos_x_out; a.pos_t = pos_t_out; a.vars = vars_out; a.feat = feat_out;
+    for (int c = 0; c < n_cols; ++c) {
+        MSMP_REQUIRE(cols[c] && col_div[c] != 0.0, MSMP_ERR_ARG, "msmp_prepare_nodes: bad column %d", c);
+        a.col[c] = cols[c]; a.col_f64[c] = col_f64[c]; a.col_div[c] = col_div[c];
+    }
+    const long total = (long)n_nodes * stride;
+    hipLaunchKernelGGL(prepare_nodes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("prepare_nodes_kernel");
 }
 
 extern "C" int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int64_t n_edges, int tile_nodes,

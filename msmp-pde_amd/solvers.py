@@ -140,6 +140,53 @@ class _SolverBase(nn.Module):
         return 'GNN'     # every helper of the reference dispatches on this (train_helper.py:99,110,124,...)
 
     # -- feature preparation -----------------------------------------------------------------
+    def _variable_columns(self, data):
+        """(tensor [N,1], divisor) of every equation-variable column after pos_t, in the reference's order."""
+        ev = self.eq_variables
+        cols = []
+        if self.TWO_D:      # models_gnn2D.py:112-116 -- NB 'b' divides data.a (reference behaviour, kept)
+            if 'a' in ev:
+                cols.append((data.a, ev['a']))
+            if 'b' in ev:
+                cols.append((data.a, ev['b']))
+        else:               # models_gnn.py:250-266
+            for k in ('alpha', 'beta', 'gamma'):
+                if k in ev:
+                    cols.append((getattr(data, k), ev[k]))
+            for k in ('bc_left', 'bc_right'):
+                if k in ev:
+                    cols.append((getattr(data, k), 1))
+            for k in ('c', 'D', 'r'):
+                if k in ev:
+                    cols.append((getattr(data, k), ev[k]))
+        return cols
+
+    def _prepare(self, data, want_feat):
+        """u, pos_x [N,1], pos_t [N,1], variables [N,nv] (float32) and the packed feature rows of the tile kernel from one HIP
+        launch (msmp_prepare_nodes); same values as the tensor expressions of the reference's forward (:1325-1352)."""
+        import ctypes
+        x, pos = data.x, data.pos
+        cols = self._variable_columns(data)
+        ok = lambda t: t.is_cuda and t.dtype in (torch.float32, torch.float64)
+        if not (ok(x) and ok(pos) and all(ok(c) for c, _ in cols)):
+            return None
+        x, pos = x.contiguous(), pos.contiguous()
+        cs = [c.reshape(-1).contiguous() for c, _ in cols]
+        n, tw_feat, nc = x.shape[0], x.shape[1], len(cs)
+        dev = x.device
+        L = lib()
+        u = torch.empty(n, tw_feat, dtype=torch.float32, device=dev)
+        pos_x = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        pos_t = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        variables = torch.empty(n, 1 + nc, dtype=torch.float32, device=dev)
+        feat = torch.empty(n, L.msmp_node_feature_stride(tw_feat, 1 + nc), dtype=torch.float32, device=dev) if want_feat else None
+        check(L.msmp_prepare_nodes(ptr(x), int(x.dtype == torch.float64), ptr(pos), int(pos.dtype == torch.float64), n, tw_feat,
+                                   float(self.pde.L), float(self.pde.tmax), nc, (ctypes.c_void_p * max(nc, 1))(*[ptr(c) for c in cs]),
+                                   (ctypes.c_int * max(nc, 1))(*[int(c.dtype == torch.float64) for c in cs]),
+                                   (ctypes.c_double * max(nc, 1))(*[float(d) for _, d in cols]), ptr(u), ptr(pos_x), ptr(pos_t),
+                                   ptr(variables), ptr(feat), current_stream()), 'msmp_prepare_nodes')
+        return u, pos_x, pos_t, variables, feat
+
     def _variables(self, data, pos_t):
         ev = self.eq_variables
         cols = [pos_t]
@@ -223,18 +270,26 @@ class _SolverBase(nn.Module):
     def forward(self, data):
         u_in = data.x
         pos = data.pos
-        pos_x = (pos[:, 1][:, None] / self.pde.L)
-        pos_t = (pos[:, 0][:, None] / self.pde.tmax)
-        variables = self._variables(data, pos_t).float()
-        pos_x, pos_t = pos_x.float(), pos_t.float()
-        u = u_in.float().contiguous()
         gs = structure_of(data)
         tw = self.time_window
-        dt = torch.cumsum(torch.ones(tw, dtype=torch.float32, device=u.device) * self.pde.dt, 0)
+        # the [u | pos | vars] columns of message_net_1's input do not change over the layers: packed once for the tile kernel
+        want_feat = not torch.is_grad_enabled() and gs.tiles() is not None
+        prep = self._prepare(data, want_feat) if u_in.is_cuda else None
+        if prep is not None:            # one HIP launch
+            u, pos_x, pos_t, variables, feat = prep
+        else:                           # odd dtypes: the tensor expressions of the reference
+            pos_x = (pos[:, 1][:, None] / self.pde.L)
+            pos_t = (pos[:, 0][:, None] / self.pde.tmax)
+            variables = self._variables(data, pos_t).float()
+            pos_x, pos_t = pos_x.float(), pos_t.float()
+            u = u_in.float().contiguous()
+            feat = node_features(u, pos_x.reshape(-1).contiguous(), variables.contiguous()) if want_feat else None
+        dkey = (tw, float(self.pde.dt), str(u.device))
+        if getattr(self, '_dt_key', None) != dkey:       # cumsum(dt) of the Euler update: constant until pde.dt changes
+            self._dt_cum, self._dt_key = torch.cumsum(torch.ones(tw, dtype=torch.float32, device=u.device) * self.pde.dt, 0), dkey
+        dt = self._dt_cum
 
         h = self._encode(u, pos_x, pos_t, variables, dt)
-        # the [u | pos | vars] columns of message_net_1's input do not change over the layers: packed once for the tile kernel
-        feat = node_features(u, pos_x.reshape(-1).contiguous(), variables.contiguous()) if (not torch.is_grad_enabled() and gs.tiles() is not None) else None
         for i in range(self.hidden_layer):
             if self.G2:
                 h = self._g2_pair(h, u, pos_x, variables, gs, i)

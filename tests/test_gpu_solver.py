@@ -250,6 +250,26 @@ def test_captured_forward_survives_workspace_growth_and_weight_updates(mp):
         assert torch.equal(step(g_small), ref2)
 
 
+@pytest.mark.parametrize('kind,exp', [('MP_PDE_SolverLEMLinGated', 'E2'), ('MP_PDE_SolverGated', 'WE3'), ('MP_PDE_Solver2DLEMLinGated', 'RPU')])
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_fused_feature_preparation_is_bit_identical(mp, kind, exp, dtype):
+    """msmp_prepare_nodes (one launch) against the tensor expressions of the reference's forward (models_gnn.py:1325-1352): u, pos_x,
+    pos_t, variables and the packed feature rows, for float64 graphs (the reference's dtype) and float32 ones, bit for bit."""
+    from msmp_pde_amd.layers import node_features
+    case = synthetic_case(mp, exp, bsz=3, seed=2)
+    model = getattr(mp, kind)(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=1).cuda().eval()
+    data = case.graph.to('cuda')
+    for k, v in list(data.__dict__.items()):
+        if torch.is_tensor(v) and v.is_floating_point():
+            setattr(data, k, v.to(dtype))
+    u, pos_x, pos_t, variables, feat = model._prepare(data, True)
+    rx = (data.pos[:, 1][:, None] / case.pde.L)
+    rt = (data.pos[:, 0][:, None] / case.pde.tmax)
+    rv = model._variables(data, rt).float()
+    assert torch.equal(u, data.x.float()) and torch.equal(pos_x, rx.float()) and torch.equal(pos_t, rt.float()) and torch.equal(variables, rv)
+    assert torch.equal(feat, node_features(u, pos_x.reshape(-1).contiguous(), variables))
+
+
 def test_fails_loudly_without_gpu_tensors(mp):
     case = synthetic_case(mp, 'E2', bsz=2, seed=1, device='cpu')
     model = mp.MP_PDE_Solver(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=1)

@@ -52,6 +52,7 @@ def test_argument_errors_are_reported_not_thrown(mp):
     assert L.msmp_edge_aggregate_tiled_f32(*([None] * 9), 10, 20, 25, 2, None, None, None) == -1
     assert L.msmp_pack_node_features_f32(None, None, None, 10, 25, 2, None, None) == -1 and L.msmp_node_feature_stride(25, 2) == 32 and L.msmp_node_feature_stride(50, 3) == 64
     assert L.msmp_mlp2_swish_f32(None, 10, 28, None, None, None) == -1
+    assert L.msmp_prepare_nodes(None, 0, None, 0, 10, 25, 16.0, 4.0, 0, None, None, None, None, None, None, None, None, None) == -1
     assert L.msmp_adamw_f32(3, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, None) == -1
     assert L.msmp_lem_encoder_nodes_f32(*([None] * 5), 10, 25, 2, 0, 1.0, None, 1, None, None) == -1
     assert L.msmp_decoder2d_f32(None, None, 10, 25, None, None, None, None, 0.016, None, None) == -1
