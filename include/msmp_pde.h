@@ -164,13 +164,16 @@ typedef struct {
     int32_t n_tiles;             /* ceil(n_nodes / tile_nodes) */
     const int32_t* tile_node;    /* [n_tiles][MSMP_TILE_NCAP] node ids (unused slots repeat the tile's first node) */
     const int32_t* tile_count;   /* [n_tiles] number of valid slots */
+    const int32_t* tile_halo;    /* [n_tiles][4]: (lo start, lo count, hi start, hi count) when the tile's sources outside it are one
+                                  * run of consecutive nodes below and one above (slots then follow node order and the kernel needs
+                                  * no list lookup); lo count = -1 otherwise */
     const int32_t* edge_slot;    /* [E] per CSR edge: target slot | source slot << 8 */
 } msmp_tiles_t;
 /* stats_out (device, 2 x int32): largest node list, largest edge count over the tiles (lists longer than MSMP_TILE_NCAP are
  * truncated in the output: the structure is then not usable with this tile_nodes). */
 int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int64_t n_edges, int tile_nodes,
-                     int32_t* tile_node_out, int32_t* tile_count_out, int32_t* edge_slot_out, int32_t* stats_out,
-                     msmp_stream_t stream);
+                     int32_t* tile_node_out, int32_t* tile_count_out, int32_t* tile_halo_out, int32_t* edge_slot_out,
+                     int32_t* stats_out, msmp_stream_t stream);
 /* L1 + L2 on node tiles: same result as msmp_edge_aggregate_projected_f32 (p, q given: the tile's P / Q rows are staged in
  * LDS) or, with p == q == NULL, as msmp_node_project_f32 + msmp_edge_aggregate_projected_f32 in ONE launch: the tile's h / u /
  * pos / vars rows are staged in LDS, P and Q of the tile's nodes are computed there (halo nodes recomputed per tile) and never

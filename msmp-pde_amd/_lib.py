@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get('MSMP_LIB_PATH') or os.path.join(PKG, 'libmsmp_pde.so'
 class MsmpTiles(ctypes.Structure):
     """msmp_tiles_t (include/msmp_pde.h): node tiles of the LDS-staged message kernel."""
     _fields_ = [('tile_nodes', ctypes.c_int32), ('n_tiles', ctypes.c_int32), ('tile_node', c_void_p), ('tile_count', c_void_p),
-                ('edge_slot', c_void_p)]
+                ('tile_halo', c_void_p), ('edge_slot', c_void_p)]
 
 
 MSMP_TILE_NCAP = 32
@@ -42,7 +42,7 @@ SIGNATURES = {
     'msmp_edge_aggregate_f32': (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'msmp_node_project_f32': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'msmp_edge_aggregate_projected_f32': (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    'msmp_build_tiles': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'msmp_build_tiles': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'msmp_node_feature_stride': (c_int, [c_int, c_int]),
     'msmp_prepare_nodes': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

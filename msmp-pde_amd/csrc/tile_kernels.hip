@@ -56,10 +56,12 @@ __device__ __forceinline__ float node_scaled(float x) { return __builtin_amdgcn_
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int n_nodes,
                                                           int tile_nodes, int* __restrict__ tile_node, int* __restrict__ tile_count,
-                                                          int* __restrict__ edge_slot, int* __restrict__ stats) {
+                                                          int* __restrict__ tile_halo, int* __restrict__ edge_slot,
+                                                          int* __restrict__ stats) {
     __shared__ int s_col[TILE_EDGES];
     __shared__ int s_first[TILE_EDGES];     // 1: first occurrence of an out-of-range source
     __shared__ int s_slot[TILE_EDGES];
+    __shared__ int s_halo[5];               // lo start, lo count, hi start, hi count, ranged
     const int t = blockIdx.x, k = threadIdx.x;
     const int n0 = t * tile_nodes, n1 = min(n0 + tile_nodes, n_nodes);
     const int e0 = rowptr[n0], e1 = rowptr[n1];
@@ -77,9 +79,27 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
     }
     s_first[k] = first;
     __syncthreads();
+    // "Ranged" tile: the sources outside the tile form at most one run of consecutive nodes below it and one above it (every
+    // interior tile of a banded 1-D graph).  Their slots are then numbered in ascending node order and the message kernel
+    // computes the node of a slot ARITHMETICALLY from four integers it reads with one scalar load (tile_halo), instead of reading
+    // the node list first and the rows second (two dependent global reads at the head of every tile).
+    if (k == 0) {
+        int lo_min = 0x7fffffff, lo_max = -1, lo_cnt = 0, hi_min = 0x7fffffff, hi_max = -1, hi_cnt = 0;
+        for (int i = 0; i < nek; ++i)
+            if (s_first[i]) {
+                const int v = s_col[i];
+                if (v < n0) { lo_min = min(lo_min, v); lo_max = max(lo_max, v); ++lo_cnt; }
+                else { hi_min = min(hi_min, v); hi_max = max(hi_max, v); ++hi_cnt; }
+            }
+        const bool ranged = (lo_cnt == 0 || lo_max - lo_min + 1 == lo_cnt) && (hi_cnt == 0 || hi_max - hi_min + 1 == hi_cnt);
+        s_halo[0] = lo_cnt ? lo_min : 0; s_halo[1] = lo_cnt; s_halo[2] = hi_cnt ? hi_min : 0; s_halo[3] = hi_cnt; s_halo[4] = ranged;
+    }
+    __syncthreads();
+    const bool ranged = s_halo[4] != 0;
     int slot = 0;
     if (k < nek) {
         if (j >= n0 && j < n1) slot = j - n0;
+        else if (ranged) slot = j < n0 ? nt + (j - s_halo[0]) : nt + s_halo[1] + (j - s_halo[2]);
         else if (first) {
             int before = 0;
             for (int i = 0; i < k; ++i) before += s_first[i];
@@ -88,7 +108,7 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
     }
     s_slot[k] = slot;
     __syncthreads();
-    if (k < nek && !(j >= n0 && j < n1) && !first) slot = s_slot[owner];
+    if (k < nek && !(j >= n0 && j < n1) && !first && !ranged) slot = s_slot[owner];
     // outputs
     if (k < nek) {
         // target slot of edge e0 + k: the CSR row it lies in (rows of a tile are short: linear search over <= tile_nodes rows)
@@ -103,6 +123,11 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
         int total = nt;
         for (int i = 0; i < nek; ++i) total += s_first[i];
         tile_count[t] = min(total, TILE_NCAP);
+        const bool use = ranged && total <= TILE_NCAP;
+        tile_halo[4 * t + 0] = use ? s_halo[0] : 0;
+        tile_halo[4 * t + 1] = use ? s_halo[1] : -1;       // -1: not ranged, the node list decides
+        tile_halo[4 * t + 2] = use ? s_halo[2] : 0;
+        tile_halo[4 * t + 3] = use ? s_halo[3] : 0;
         atomicMax(&stats[0], total);
         atomicMax(&stats[1], ne);
     }
@@ -192,6 +217,7 @@ struct TileArgs {
     const int* rowptr;
     const int* tile_node;
     const int* tile_count;
+    const int* tile_halo;
     const int* edge_slot;
     long n_nodes, n_edges;
     int tile_nodes;
@@ -221,6 +247,15 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
     const int tile_n1 = (int)min((long)tile_n0 + a.tile_nodes, a.n_nodes);
     const int tile_e0 = a.rowptr[tile_n0], tile_e1 = a.rowptr[tile_n1];
     const int* tnode = a.tile_node + (size_t)tile * TILE_NCAP;
+    // node of a slot: arithmetic for ranged tiles (four integers from ONE scalar load), the node list otherwise
+    int h_lo = 0, h_nlo = -1, h_hi = 0, h_nhi = 0;
+    if (a.tile_halo) { h_lo = a.tile_halo[4 * tile]; h_nlo = a.tile_halo[4 * tile + 1]; h_hi = a.tile_halo[4 * tile + 2]; h_nhi = a.tile_halo[4 * tile + 3]; }
+    const int nt_ = tile_n1 - tile_n0;
+    auto node_of = [&](int slot) -> int {
+        if (h_nlo < 0) return tnode[slot];
+        const int r = slot - nt_;
+        return r < 0 ? tile_n0 + slot : (r < h_nlo ? h_lo + r : (r < h_nlo + h_nhi ? h_hi + (r - h_nlo) : tile_n0));
+    };
 
     // this lane's edge and its two LDS rows
     const int e = tile_e0 + wave * 32 + c;
@@ -240,7 +275,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int slot = (tid >> 5) + 8 * i;
-            const int node = tnode[slot];
+            const int node = node_of(slot);
             pv[i] = *reinterpret_cast<const f32x4*>(a.P + (size_t)node * H + 4 * piece) * ACT_SCALE;
             qv[i] = *reinterpret_cast<const f32x4*>(a.Q + (size_t)node * H + 4 * piece) * ACT_SCALE;
         }
@@ -260,16 +295,34 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         _Float16* bt = reinterpret_cast<_Float16*>(wbuf);
         using half4 = __attribute__((ext_vector_type(4))) _Float16;
         const int ntail = a.nc1 - 8;
+        // fragment (s, plane) of chunk `ch`, row tile `wave`: lane-linear 16 bytes
+        // one 32-bit lane offset + a uniform base per fragment (scalar base + vector offset addressing): written as 40 separate
+        // 64-bit pointers the loop-invariant addresses were hoisted out of the tile loop and spilled
+        unsigned woff = (unsigned)((wave * 2 * 64 + lane) * 16);
+        asm volatile("" : "+v"(woff));
+        auto wfrag = [&](int ch, int s, int plane) {
+            const char* base = reinterpret_cast<const char*>(a.w1s) + (size_t)ch * (SPLIT_CHUNK_FLOATS * 4) + (s * 8 + plane) * 1024;
+            return *reinterpret_cast<const half8*>(base + woff);
+        };
+        // weight fragments are requested one chunk ahead of the MFMAs that use them (they come from L2: ~1 us away)
+        half8 wp[2][2][2], wq[2][2][2];               // [buffer][K = 16 step][plane]
+        auto wload = [&](int buf, int chp, int chq) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) { wp[buf][s][p] = wfrag(chp, s, p); wq[buf][s][p] = wfrag(chq, s, p); }
+        };
+        wload(0, 0, 4);          // chunk 0 of both projections: requested before anything else, they depend on nothing
         {
             f32x4 hv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = tid + 256 * i;               // node = idx >> 5, 16-byte piece idx & 31
-                const int node = tnode[idx >> 5];
+                const int node = node_of(idx >> 5);
                 hv[i] = *reinterpret_cast<const f32x4*>(a.h + (size_t)node * H + 4 * (idx & 31));
             }
             // tail features of (node = tid >> 3, columns 4 g .. 4 g + 3 of every tail chunk), g = tid & 7
-            const int tn = tnode[tid >> 3];
+            const int tn = node_of(tid >> 3);
             const int g = tid & 7;
             float tx[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             if (packed_feat) {  // packed per-node feature rows (same for all layers of a forward): one 16-byte load per tail chunk
@@ -346,15 +399,6 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accP[r] = bv; accQ[r] = 0.f; }
         }
-        // fragment (s, plane) of chunk `ch`, row tile `wave`: lane-linear 16 bytes
-        // one 32-bit lane offset + a uniform base per fragment (scalar base + vector offset addressing): written as 40 separate
-        // 64-bit pointers the loop-invariant addresses were hoisted out of the tile loop and spilled
-        unsigned woff = (unsigned)((wave * 2 * 64 + lane) * 16);
-        asm volatile("" : "+v"(woff));
-        auto wfrag = [&](int ch, int s, int plane) {
-            const char* base = reinterpret_cast<const char*>(a.w1s) + (size_t)ch * (SPLIT_CHUNK_FLOATS * 4) + (s * 8 + plane) * 1024;
-            return *reinterpret_cast<const half8*>(base + woff);
-        };
         auto afrag = [&](int ch, half8 (&ahi)[2], half8 (&alo)[2]) {
             const _Float16* row = bt + (ch * 32 + c) * BROW_T + 8 * hh;
 #pragma unroll
@@ -368,15 +412,6 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, whi, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi, acc, 0, 0, 0);
         };
-        // weight fragments are requested one chunk ahead of the MFMAs that use them (they come from L2: ~1 us away)
-        half8 wp[2][2][2], wq[2][2][2];               // [buffer][K = 16 step][plane]
-        auto wload = [&](int buf, int chp, int chq) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) { wp[buf][s][p] = wfrag(chp, s, p); wq[buf][s][p] = wfrag(chq, s, p); }
-        };
-        wload(0, 0, 4);
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             const int cur = ch & 1;
@@ -664,9 +699,10 @@ extern "C" int msmp_prepare_nodes(const void* x, int x_f64, const void* pos, int
 }
 
 extern "C" int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int64_t n_edges, int tile_nodes,
-                                int32_t* tile_node_out, int32_t* tile_count_out, int32_t* edge_slot_out, int32_t* stats_out,
-                                msmp_stream_t stream) {
-    MSMP_REQUIRE(rowptr && col && tile_node_out && tile_count_out && edge_slot_out && stats_out, MSMP_ERR_ARG, "msmp_build_tiles: null pointer");
+                                int32_t* tile_node_out, int32_t* tile_count_out, int32_t* tile_halo_out, int32_t* edge_slot_out,
+                                int32_t* stats_out, msmp_stream_t stream) {
+    MSMP_REQUIRE(rowptr && col && tile_node_out && tile_count_out && tile_halo_out && edge_slot_out && stats_out, MSMP_ERR_ARG,
+                 "msmp_build_tiles: null pointer");
     MSMP_REQUIRE(n_nodes > 0 && n_edges >= 0 && n_nodes < (1L << 31) && n_edges < (1L << 31), MSMP_ERR_ARG, "msmp_build_tiles: bad sizes");
     MSMP_REQUIRE(tile_nodes >= 1 && tile_nodes <= MSMP_TILE_NCAP, MSMP_ERR_ARG, "msmp_build_tiles: tile_nodes must be in 1..%d", MSMP_TILE_NCAP);
     hipStream_t st = (hipStream_t)stream;
@@ -674,7 +710,7 @@ extern "C" int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64
     MSMP_REQUIRE(me == hipSuccess, MSMP_ERR_HIP, "msmp_build_tiles: memset: %s", hipGetErrorString(me));
     const unsigned n_tiles = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
     hipLaunchKernelGGL(build_tiles_kernel, dim3(n_tiles), dim3(128), 0, st, rowptr, col, (int)n_nodes, tile_nodes, tile_node_out,
-                       tile_count_out, edge_slot_out, stats_out);
+                       tile_count_out, tile_halo_out, edge_slot_out, stats_out);
     return check_launch("build_tiles_kernel");
 }
 
@@ -686,7 +722,7 @@ extern "C" int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, con
     MSMP_REQUIRE((p != nullptr) == (q != nullptr), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: give both of p, q or neither");
     const bool fold = p == nullptr;
     MSMP_REQUIRE(!fold || (h && u && pos && vars), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: null pointer (h, u, pos, vars)");
-    MSMP_REQUIRE(tiles->tile_node && tiles->tile_count && tiles->edge_slot && tiles->tile_nodes >= 1 && tiles->tile_nodes <= MSMP_TILE_NCAP,
+    MSMP_REQUIRE(tiles->tile_node && tiles->tile_count && tiles->tile_halo && tiles->edge_slot && tiles->tile_nodes >= 1 && tiles->tile_nodes <= MSMP_TILE_NCAP,
                  MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: bad tile descriptor");
     MSMP_REQUIRE(n_nodes > 0 && n_edges >= 0 && n_nodes < (1L << 31) && n_edges < (1L << 31) && tw > 0 && nv >= 1 && nv <= MSMP_MAX_VARS,
                  MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: bad sizes");
@@ -695,7 +731,7 @@ extern "C" int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, con
     MSMP_REQUIRE(msmp_tune_get("split"), MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_f32: only on the fp16-split matrix path");
     const PackedLayout L = packed_layout(tw, nv);
     MSMP_REQUIRE(!fold || L.nc1 - 8 <= 2, MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_f32: tw + 1 + nv <= 64");
-    TileArgs a{h, u, pos, vars, feat, p, q, rowptr, tiles->tile_node, tiles->tile_count, tiles->edge_slot, (long)n_nodes, (long)n_edges,
+    TileArgs a{h, u, pos, vars, feat, p, q, rowptr, tiles->tile_node, tiles->tile_count, msmp_tune_get("tile_arith") ? tiles->tile_halo : nullptr, tiles->edge_slot, (long)n_nodes, (long)n_edges,
                tiles->tile_nodes, tw, nv, L.nc1, packed + L.w1s, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, agg_out};
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_EDGE_MLP, st);
@@ -719,7 +755,7 @@ int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* 
     const float* packed[2] = {packed_a, packed_b};
     float* agg[2] = {agg_a, agg_b};
     for (int i = 0; i < 2; ++i)
-        a2.head[i] = TileArgs{h, u, pos, vars, feat, nullptr, nullptr, rowptr, tiles->tile_node, tiles->tile_count, tiles->edge_slot, (long)n_nodes,
+        a2.head[i] = TileArgs{h, u, pos, vars, feat, nullptr, nullptr, rowptr, tiles->tile_node, tiles->tile_count, msmp_tune_get("tile_arith") ? tiles->tile_halo : nullptr, tiles->edge_slot, (long)n_nodes,
                               (long)n_edges, tiles->tile_nodes, tw, nv, L.nc1, packed[i] + L.w1s, packed[i] + L.w2s, packed[i] + L.scales,
                               packed[i] + L.b1, packed[i] + L.b2, agg[i]};
     hipStream_t st = (hipStream_t)stream;

@@ -91,14 +91,15 @@ class GraphStructure(object):
             n_tiles = (self.n_nodes + tn - 1) // tn
             tile_node = torch.empty(n_tiles * _lib.MSMP_TILE_NCAP, dtype=torch.int32, device=dev)
             tile_count = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+            tile_halo = torch.empty(n_tiles * 4, dtype=torch.int32, device=dev)
             edge_slot = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
             stats = torch.empty(2, dtype=torch.int32, device=dev)
             check(L.msmp_build_tiles(ptr(self.rowptr), ptr(self.col), self.n_nodes, self.n_edges, tn, ptr(tile_node), ptr(tile_count),
-                                     ptr(edge_slot), ptr(stats), current_stream()), 'msmp_build_tiles')
+                                     ptr(tile_halo), ptr(edge_slot), ptr(stats), current_stream()), 'msmp_build_tiles')
             max_nodes, max_edges = (int(v) for v in stats.tolist())
             if max_nodes <= _lib.MSMP_TILE_NCAP and max_edges <= _lib.MSMP_TILE_EDGES:
-                desc = _lib.MsmpTiles(tn, n_tiles, ptr(tile_node), ptr(tile_count), ptr(edge_slot))
-                self._tiles = (desc, tile_node, tile_count, edge_slot)      # the tensors keep the descriptor's memory alive
+                desc = _lib.MsmpTiles(tn, n_tiles, ptr(tile_node), ptr(tile_count), ptr(tile_halo), ptr(edge_slot))
+                self._tiles = (desc, tile_node, tile_count, edge_slot, tile_halo)      # the tensors keep the descriptor's memory alive
                 return self._tiles
             tn = min(tn - 1, tn - (max_nodes - _lib.MSMP_TILE_NCAP)) if max_nodes > _lib.MSMP_TILE_NCAP else tn - 1
         return None

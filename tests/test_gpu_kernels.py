@@ -583,7 +583,8 @@ def test_node_tiles_are_a_valid_cover(mp, exp, bsz, nx, neighbors):
     c, graph, gs = _tile_case(mp, exp, bsz, nx, neighbors)
     t = gs.tiles()
     assert t is not None, 'the banded 1-D graphs of the four experiments must tile'
-    desc, tile_node, tile_count, edge_slot = t
+    desc, tile_node, tile_count, edge_slot, tile_halo = t
+    tile_halo = tile_halo.cpu().numpy().reshape(-1, 4)
     tn, n_tiles = desc.tile_nodes, desc.n_tiles
     rowptr, col = gs.rowptr.cpu().numpy(), gs.col.cpu().numpy()[:gs.n_edges]
     tile_node = tile_node.cpu().numpy().reshape(n_tiles, _lib.MSMP_TILE_NCAP)
@@ -602,6 +603,13 @@ def test_node_tiles_are_a_valid_cover(mp, exp, bsz, nx, neighbors):
         tgt_of_edge = np.searchsorted(rowptr, np.arange(e0, e1), side='right') - 1
         assert np.array_equal(n0 + (edge_slot[e0:e1] & 255), tgt_of_edge)
         assert np.array_equal(nodes[(edge_slot[e0:e1] >> 8) & 255], col[e0:e1])
+        lo, nlo, hi, nhi = tile_halo[ti]
+        if nlo >= 0:        # ranged tile: the list is [targets | lo run | hi run], which the kernel reproduces arithmetically
+            want = np.concatenate([np.arange(n0, n1), np.arange(lo, lo + nlo), np.arange(hi, hi + nhi)])
+            assert np.array_equal(nodes[:tile_count[ti]], want)
+    if exp in ('E2', 'MSWG3', 'WE3'):
+        assert (tile_halo[:, 1] >= 0).all(), 'every tile of a banded graph without wrap-around is ranged'
+    print(f'{exp}: {int((tile_halo[:, 1] >= 0).sum())} of {n_tiles} tiles ranged, tile_nodes {tn}')
 
 
 def test_irregular_graph_does_not_tile(mp):

@@ -48,7 +48,7 @@ def test_argument_errors_are_reported_not_thrown(mp):
     assert rc == -1
     # every new entry point of this round validates its arguments the same way (no device work happens on these calls)
     assert L.msmp_node_tail_f32(*([None] * 5), 10, 1, 100, 2, None, None, 1, 1e-5, None, None) == -1
-    assert L.msmp_build_tiles(None, None, 10, 20, 21, None, None, None, None, None) == -1
+    assert L.msmp_build_tiles(None, None, 10, 20, 21, None, None, None, None, None, None) == -1
     assert L.msmp_edge_aggregate_tiled_f32(*([None] * 9), 10, 20, 25, 2, None, None, None) == -1
     assert L.msmp_pack_node_features_f32(None, None, None, 10, 25, 2, None, None) == -1 and L.msmp_node_feature_stride(25, 2) == 32 and L.msmp_node_feature_stride(50, 3) == 64
     assert L.msmp_mlp2_swish_f32(None, 10, 28, None, None, None) == -1
