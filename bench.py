@@ -276,14 +276,23 @@ def run_rank(args):
     k_msg = model.gnn_layers[0].message_net_1[0].in_features        # 2H + Tw + 1 + nv (Tw = 2*tw for the *2D classes)
     # Row L1 (message MLP) in the reference's dense formulation: 2*E*K_msg*H + 2*E*H*H per layer.
     flop_l1_dense = 2.0 * n_edges * k_msg * H + 2.0 * n_edges * H * H
-    # What the message kernel itself executes in the factorised form: message_net_2 only (message_net_1 became per-node projections).
-    flop_edge_exec = 2.0 * n_edges * H * H
     n_launch, ms_total = timing['edge']
     n_proj, ms_proj = timing['proj']
     t_launch = ms_total / max(n_launch, 1) * 1e-3
     t_proj = ms_proj / max(n_proj, 1) * 1e-3
-    factorised = n_proj > 0
-    flop_exec = flop_edge_exec if factorised else flop_l1_dense
+    # Which form ran: `folded` = node tiles staged in LDS, P / Q projected inside the message kernel;
+    # `factorised` = separate projection kernel; else the literal per-edge GEMM.
+    from msmp_pde_amd.graph import structure_of
+    tiles = structure_of(graph).tiles()
+    folded = tiles is not None and n_proj == 0 and L.msmp_tune_query(b'tile') == 2 and split_path
+    factorised = folded or n_proj > 0
+    k_tail = 32 * ((k_msg - 2 * H + 31) // 32)                      # [u | pos | vars] columns, padded to whole chunks
+    flop_gemm2 = 2.0 * n_edges * H * H                              # message_net_2: the per-edge GEMM that remains
+    flop_proj_alg = 2.0 * n_nodes * 2 * (H + k_tail) * H            # P and Q of every node once (what the projection kernel executes)
+    # useful fp32 FLOPs of the dominant kernel per launch (no halo recomputation, no padding)
+    flop_exec = (flop_gemm2 + flop_proj_alg) if folded else (flop_gemm2 if factorised else flop_l1_dense)
+    # what the matrix pipe really executes in the folded kernel: one 32-slot node block per tile (halo nodes recomputed, slots padded)
+    flop_pipe = (flop_gemm2 + 2.0 * tiles[0].n_tiles * 32 * 2 * (H + k_tail) * H) if folded else flop_exec
     achieved = flop_exec / t_launch / 1e12 if n_launch else None
     alg_tflops = flop_l1_dense / (t_launch + t_proj) / 1e12 if n_launch else None
     # HBM traffic of the dominant kernel: PMC passes of scripts/profile_gpu.sh, valid only for the sources and workload they were taken on
@@ -305,7 +314,7 @@ def run_rank(args):
     peak_eq = PEAK_FP16_MFMA_TFLOPS / 3.0 if split_path else PEAK_FP32_MFMA_TFLOPS
     # algorithmic HBM bytes of the fused message + mean launch (SURVEY 8d "fused layer" accounting for this kernel's share):
     # read the node rows it consumes once, the CSR, write the aggregate
-    alg_bytes = (2 * n_nodes * H * 4 if n_proj > 0 else n_nodes * (H + k_msg - 2 * H) * 4) + n_edges * 8 + (n_nodes + 1) * 4 + n_nodes * H * 4
+    alg_bytes = ((2 * n_nodes * H * 4) if (factorised and not folded) else n_nodes * (H + k_msg - 2 * H) * 4) + n_edges * 4 + (n_nodes + 1) * 4 + n_nodes * H * 4
     frac_mfma = (achieved / peak_eq) if achieved else None
     frac_hbm = (alg_bytes / t_launch / 1e9 / PEAK_HBM_GBPS) if n_launch else None
     out = {
@@ -320,14 +329,15 @@ def run_rank(args):
                    'parallelism': f'dp{world} (graph-sharded, no collective in the rollout)',
                    'graph_steps_per_s': head['graph_steps_per_s'], 'output_finite': head['output_finite'],
                    'preheat': f'{head["preheat_steps"]} untimed steps (>= {args.preheat_s:g} s) after the {args.warmup} warm-up steps'},
-        # `achieved` counts the fp32 GEMM FLOPs the dominant kernel computes (the factorised form removed 69 % of row L1's dense
-        # FLOPs).  They execute on the fp16 matrix pipe (2-way fp16 split of both operands, 3 MFMAs per K=16 step, fp32-class
+        # `achieved` counts the USEFUL fp32 GEMM FLOPs the dominant kernel computes (message_net_2 per edge + the per-node projections
+        # once per node; the factorised form removed 69 % of row L1's dense FLOPs).  They execute on the fp16 matrix pipe (2-way fp16 split of both operands, 3 MFMAs per K=16 step, fp32-class
         # accuracy), so `peak` is that pipe's dense peak / 3 and `frac` equals the literal f16-MFMA utilisation (`matrix_pipe`).
         # `bound` names the nearer of the two rooflines; `bound_detail` says what the phase profile shows actually limits it.
         'roofline': {'bound': 'mfma' if (frac_mfma or 0) >= (frac_hbm or 0) else 'hbm',
                      'bound_detail': 'neither roof: see DESIGN.md section 4 (phase profile: node-row gather latency, LDS port and activation VALU; matrix pipe and HBM both under 0.4)',
                      'kernel': 'edge message kernel (message_net_2 + Swish + per-target mean'
-                     + (', factorised message_net_1' if factorised else ', dense message_net_1')
+                     + (', node tiles staged in LDS with the per-node projections of message_net_1 folded in' if folded
+                        else ', factorised message_net_1 (separate projection kernel)' if factorised else ', dense message_net_1')
                      + ('; fp32 GEMM on the fp16 matrix pipe via 2-way fp16 split)' if split_path else '; fp32 MFMA)'),
                      'achieved': achieved, 'peak': peak_eq,
                      'unit': 'TFLOP/s', 'frac': frac_mfma,
@@ -338,8 +348,9 @@ def run_rank(args):
                              'peak_GBps': PEAK_HBM_GBPS, 'frac': frac_hbm},
                      'traffic': traffic, 'traffic_note': traffic_note, 'launches': n_launch, 'avg_launch_ms': t_launch * 1e3,
                      'executed_gflop_per_launch': flop_exec / 1e9,
-                     'matrix_pipe': ({'dtype': 'f16 (3 MFMAs per fp32 K=16 step)', 'executed_tflops': 3 * achieved,
-                                      'peak_tflops': PEAK_FP16_MFMA_TFLOPS, 'frac': 3 * achieved / PEAK_FP16_MFMA_TFLOPS}
+                     'matrix_pipe': ({'dtype': 'f16 (3 MFMAs per fp32 K=16 step)', 'executed_tflops': 3 * flop_pipe / t_launch / 1e12,
+                                      'peak_tflops': PEAK_FP16_MFMA_TFLOPS, 'frac': 3 * flop_pipe / t_launch / 1e12 / PEAK_FP16_MFMA_TFLOPS,
+                                      'note': 'everything the pipe executes, incl. halo recomputation and padded node slots of the folded projections'}
                                      if split_path and achieved else None),
                      'algorithmic': {'row': 'L1+L2 message MLP + mean = node projection + message kernels per layer',
                                      'gflop_per_layer': flop_l1_dense / 1e9, 'ms_per_layer': (t_launch + t_proj) * 1e3,

@@ -26,6 +26,7 @@ SIGNATURES = {
     'msmp_version': (c_int, []),
     'msmp_last_error': (c_char_p, []),
     'msmp_tune': (c_int, [c_char_p, c_int]),
+    'msmp_tune_query': (c_int, [c_char_p]),
     'msmp_packed_layer_floats': (c_int64, [c_int, c_int]),
     'msmp_pack_layer_f32': (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p, c_void_p]),
     'msmp_build_csr_workspace_bytes': (c_size_t, [c_int64, c_int64]),

@@ -1299,6 +1299,8 @@ int msmp_tune_get(const char* key) {
     return 0;
 }
 
+extern "C" int msmp_tune_query(const char* key) { return key ? msmp_tune_get(key) : 0; }
+
 extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "tail")) { g_tail = value; return MSMP_OK; }
     if (key && !strcmp(key, "pair")) { g_pair = value; return MSMP_OK; }
