@@ -24,7 +24,9 @@ namespace msmp {
 __device__ unsigned long long g_prof_tile[16];
 #define TPROF_DECL unsigned pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned tp = (unsigned)__builtin_readcyclecounter();
 #define TPROF(i) do { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); pacc[i] += t_ - tp; tp = t_; } while (0)
-#define TPROF_FLUSH if (tid == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_prof_tile[i_], (unsigned long long)pacc[i_]);
+// one workgroup in 64 reports (every workgroup adding to the same 12 words turns the counters' L2 channel into a hot spot that
+// slows the weight loads of ALL workgroups: the profile of round 2's first edition showed 2-3 x inflated load phases)
+#define TPROF_FLUSH if (tid == 0 && (blockIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_prof_tile[i_], (unsigned long long)pacc[i_]); atomicAdd(&g_prof_tile[15], 1ull); }
 #else
 #define TPROF_DECL
 #define TPROF(i)
@@ -35,8 +37,6 @@ constexpr int TILE_NCAP = MSMP_TILE_NCAP;
 constexpr int TILE_EDGES = MSMP_TILE_EDGES;
 constexpr int PQLD = H + 4;                       // LDS row stride of a staged P / Q row (floats): 33 x 16 B
 constexpr int BROW_T = 72;                        // halfs per staged fragment row: [hi 32 | lo 32] + 16 B pad (as node_proj's B tile)
-constexpr int WBUF_FLOATS = 2 * H * LDW;          // weight double buffer / epilogue staging / (FOLD) fragment tile: 36 864 B
-constexpr int TILE_LDS_FLOATS = WBUF_FLOATS + 2 * TILE_NCAP * PQLD;
 // Activations enter the fp16-split GEMMs multiplied by 2^6.  The low half of a value x is fp16(x - fp16(x)) ~ 2^-11 x: for
 // |x| < 0.25 it falls into the fp16 subnormals (quantum 6e-8), i.e. the split then carries x with an ABSOLUTE error of 3e-8
 // instead of a relative 2^-23.  Hidden states right behind the encoder and the pre-activations of the first layers are that
@@ -230,24 +230,48 @@ struct TileArgs {
     float* agg;
 };
 
-// MODE 0: staged P / Q rows;  1: folded projections, features read from u / pos / vars;  2: folded, packed feature rows
+// ------------------------------------------------------------------------------------------------------------------------
+// The tile body.  MODE 0: staged P / Q rows;  1: folded projections, features read from u / pos / vars;  2: folded, packed feature rows.
+// Cut for THREE workgroups per CU (50 176 B of LDS, <= 168 registers; round 2 measured 462 / 290 / 276 us per launch at the bench
+// size with one / two / three resident workgroups: the kernel is bound by the latency of a tile's dependent phases):
+//   * message_net_2's weights stream through LDS in HALF chunks (one K = 16 step: 8 KB), double-buffered: 2 x 8 KB;
+//   * the fp16 fragment tile of the folded projections overlays that buffer AND the head of the P / Q rows (dead until the
+//     projections are done: one barrier more than a private region would need);
+//   * the mean epilogue stages the messages in two rounds of 64 edges (33 KB), partial sums carried in registers in CSR order.
+constexpr int WHALF_FLOATS = SPLIT_CHUNK_FLOATS / 2;                            // 8 KB: one K = 16 step of a split chunk
+constexpr int WBUF_FLOATS = 2 * WHALF_FLOATS;
+constexpr int TILE_LDS_FLOATS = WBUF_FLOATS + 2 * TILE_NCAP * PQLD;      // 12 544 floats = 50 176 B
+static_assert(8 * 32 * BROW_T * 2 <= TILE_LDS_FLOATS * 4, "fragment tile of the folded projections must fit");
+static_assert((TILE_EDGES / 2) * (H + 4) <= TILE_LDS_FLOATS, "one epilogue round must fit");
+
+struct WHalf {
+    f32x4 r[2];
+};
+__device__ __forceinline__ void whalf_load(WHalf& w, const float* __restrict__ half_chunk, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w.r[i] = *reinterpret_cast<const f32x4*>(half_chunk + 4 * (tid + 256 * i));
+}
+__device__ __forceinline__ void whalf_store(const WHalf& w, float* buf, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(buf + 4 * (tid + 256 * i)) = w.r[i];
+}
+
 template <int MODE>
 __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, int n_tiles) {
     constexpr bool FOLD = MODE != 0;
-    float* wbuf = lds;                               // W2 chunks (2 x 16 KB) / epilogue staging / (FOLD) fragment tile
-    float* pl = lds + WBUF_FLOATS;                   // P rows [32][PQLD]
+    float* wbuf = lds;                               // W2 half chunks (2 x 8 KB)
+    float* pl = lds + WBUF_FLOATS;             // P rows [32][PQLD]
     float* ql = pl + TILE_NCAP * PQLD;               // Q rows [32][PQLD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     TPROF_DECL
-    constexpr bool packed_feat = MODE == 2;          // [u | pos | vars] rows packed once per forward (msmp_pack_node_features_f32)
+    constexpr bool packed_feat = MODE == 2;
     const int tile = blockIdx.x;
     (void)n_tiles;
     const int tile_n0 = tile * a.tile_nodes;
     const int tile_n1 = (int)min((long)tile_n0 + a.tile_nodes, a.n_nodes);
     const int tile_e0 = a.rowptr[tile_n0], tile_e1 = a.rowptr[tile_n1];
     const int* tnode = a.tile_node + (size_t)tile * TILE_NCAP;
-    // node of a slot: arithmetic for ranged tiles (four integers from ONE scalar load), the node list otherwise
     int h_lo = 0, h_nlo = -1, h_hi = 0, h_nhi = 0;
     if (a.tile_halo) { h_lo = a.tile_halo[4 * tile]; h_nlo = a.tile_halo[4 * tile + 1]; h_hi = a.tile_halo[4 * tile + 2]; h_nhi = a.tile_halo[4 * tile + 3]; }
     const int nt_ = tile_n1 - tile_n0;
@@ -257,7 +281,6 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         return r < 0 ? tile_n0 + slot : (r < h_nlo ? h_lo + r : (r < h_nlo + h_nhi ? h_hi + (r - h_nlo) : tile_n0));
     };
 
-    // this lane's edge and its two LDS rows
     const int e = tile_e0 + wave * 32 + c;
     const int ec = e < tile_e1 ? e : (tile_e1 > tile_e0 ? tile_e1 - 1 : 0);
     int sl = a.edge_slot[ec];
@@ -265,11 +288,10 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
     const float* prow = pl + (sl & 255) * PQLD + 4 * hh;
     const float* qrow = ql + ((sl >> 8) & 255) * PQLD + 4 * hh;
 
-    WStage ws;
-    wstage_load(ws, a.w2s, tid);                     // W2 chunk 0, stored once the staging region is free
+    WHalf ws;
+    whalf_load(ws, a.w2s, tid);                      // W2 chunk 0, K step 0: stored once the buffer is free
 
     if (!FOLD) {
-        // stage the tile's P / Q rows: thread (row group tid >> 5, 16-byte piece tid & 31); a row = 32 consecutive lanes = 512 B
         const int piece = tid & 31;
         f32x4 pv[4], qv[4];
 #pragma unroll
@@ -285,28 +307,21 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
             *reinterpret_cast<f32x4*>(pl + slot * PQLD + 4 * piece) = pv[i];
             *reinterpret_cast<f32x4*>(ql + slot * PQLD + 4 * piece) = qv[i];
         }
-        wstage_store_linear(ws, wbuf, tid);
+        whalf_store(ws, wbuf, tid);
         __syncthreads();
         TPROF(0);
     } else {
-        // ---- stage the tile's node rows as fp16 hi/lo fragments (natural k order) ------------------------------------
-        //   chunk ch = 0..3: h columns 32 ch .. 32 ch + 31;  chunk 4 + 2 j / 5 + 2 j: tail columns 32 j .. (P / Q variant)
-        //   row layout [node 32][hi 32 halfs | lo 32 halfs | pad] (BROW_T halfs), chunk stride 32 * BROW_T
-        _Float16* bt = reinterpret_cast<_Float16*>(wbuf);
+        // fragment tile: as in edge_tile_body, but at the START of the LDS (it overlays the weight buffer and the head of the P rows)
+        _Float16* bt = reinterpret_cast<_Float16*>(lds);
         using half4 = __attribute__((ext_vector_type(4))) _Float16;
         const int ntail = a.nc1 - 8;
-        // fragment (s, plane) of chunk `ch`, row tile `wave`: lane-linear 16 bytes
-        // one 32-bit lane offset + a uniform base per fragment (scalar base + vector offset addressing): written as 40 separate
-        // 64-bit pointers the loop-invariant addresses were hoisted out of the tile loop and spilled
         unsigned woff = (unsigned)((wave * 2 * 64 + lane) * 16);
         asm volatile("" : "+v"(woff));
         auto wfrag = [&](int ch, int s, int plane) {
             const char* base = reinterpret_cast<const char*>(a.w1s) + (size_t)ch * (SPLIT_CHUNK_FLOATS * 4) + (s * 8 + plane) * 1024;
             return *reinterpret_cast<const half8*>(base + woff);
         };
-        // weight fragments are requested one chunk ahead of the MFMAs that use them (they come from L2: ~1 us away)
-        half8 wp[3][2][2], wq[3][2][2];               // [ring slot][K = 16 step][plane]: a ring of three, two chunks in flight
-        // stream position i = 0..3: h chunk i of W1[:, 0:128] (P) and of W1[:, 128:256] (Q); i = 4: the tail chunk(s) 8 (and 9 for tw = 50)
+        half8 wp[3][2][2], wq[3][2][2];
         auto wload = [&](int i) {
             const int chp = i < 4 ? i : 8, chq = i < 4 ? 4 + i : (ntail > 1 ? 9 : 8);
 #pragma unroll
@@ -314,23 +329,20 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
 #pragma unroll
                 for (int p = 0; p < 2; ++p) { wp[i % 3][s][p] = wfrag(chp, s, p); wq[i % 3][s][p] = wfrag(chq, s, p); }
         };
-        // the first two chunks are requested before anything else (they depend on nothing): their L2 round trips overlap the index
-        // loads, the row loads and the staging below.  (All five at once measured 1.5 % SLOWER than this ring of three.)
         wload(0);
         wload(1);
         {
             f32x4 hv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int idx = tid + 256 * i;               // node = idx >> 5, 16-byte piece idx & 31
+                const int idx = tid + 256 * i;
                 const int node = node_of(idx >> 5);
                 hv[i] = *reinterpret_cast<const f32x4*>(a.h + (size_t)node * H + 4 * (idx & 31));
             }
-            // tail features of (node = tid >> 3, columns 4 g .. 4 g + 3 of every tail chunk), g = tid & 7
             const int tn = node_of(tid >> 3);
             const int g = tid & 7;
             float tx[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            if (packed_feat) {  // packed per-node feature rows (same for all layers of a forward): one 16-byte load per tail chunk
+            if (packed_feat) {
 #pragma unroll
                 for (int jc = 0; jc < 2; ++jc)
                     if (jc < ntail) {
@@ -394,9 +406,6 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         __syncthreads();
         TPROF(0);
 
-        // ---- P, Q of the tile's 32 node slots, transposed: A = node fragments (LDS), B = this wave's weight fragments ----
-        // accP / accQ [node acc_row(r, hh)][channel 32 wave + c]; weights carry 2^s (scales[0]), the node fragments NODE_SCALE; the
-        // rows written to LDS are ACT_SCALE * P, ACT_SCALE * Q (what the activation below wants).
         const float sc = a.scales[0] * NODE_SCALE, inv = a.scales[4] * (ACT_SCALE / NODE_SCALE);
         f32x16 accP, accQ;
         {
@@ -434,27 +443,25 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
             afrag(4 + 2 * jc, phi, plo);
             afrag(5 + 2 * jc, qhi, qlo);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {          // ring slot 4 % 3 = 1 after the four h chunks: wp = chunk 8, wq = chunk 9 (or 8 again)
+            for (int s = 0; s < 2; ++s) {
                 const half8 whi = jc == 0 ? wp[1][s][0] : wq[1][s][0], wlo = jc == 0 ? wp[1][s][1] : wq[1][s][1];
                 mma3(accP, phi[s], plo[s], whi, wlo);
                 mma3(accQ, qhi[s], qlo[s], whi, wlo);
             }
         }
         TPROF(1);
-        // rows of this lane: slot acc_row(r, hh), channel 32 wave + c
+        __syncthreads();                             // every wave is done with the fragment tile: the P / Q rows and the weight buffer may be written
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int slot = acc_row(r, hh);
             pl[slot * PQLD + 32 * wave + c] = accP[r] * inv;
             ql[slot * PQLD + 32 * wave + c] = accQ[r] * inv;
         }
-        __syncthreads();                             // P / Q visible; every wave is done with the fragment tile
-        wstage_store_linear(ws, wbuf, tid);
+        whalf_store(ws, wbuf, tid);
         __syncthreads();
         TPROF(2);
     }
 
-    // CSR row bounds of the nodes this thread sums in the mean epilogue: requested here, ahead of the whole matrix phase
     const int nslot = tid >> 5, cq = tid & 31;
     int r0b[4], r1b[4];
 #pragma unroll
@@ -466,13 +473,8 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         r1b[k] = node < tile_n1 ? v1 - tile_e0 : v0 - tile_e0;
     }
 
-    // ---- message_net_2 on Swish(P_i + Q_j) ---------------------------------------------------------------------------------
-    // Software pipeline, one barrier region per 32-channel K chunk t: the matrix work of chunk t (24 MFMAs = 8 groups of 3 on
-    // one accumulator each) is interleaved IN PROGRAM ORDER with the activation work of chunk t + 1 (8 slices of two values:
-    // P + Q from LDS, Swish, fp16 hi/lo split), pinned with scheduling barriers: a wave's MFMAs issue back to back while its own
-    // vector instructions fill the issue slots in between (an MFMA blocks vector issue for 8 of its 32 cycles), instead of
-    // the two phases alternating.  The A fragments of a chunk (16 x 16 B per lane) are all requested up front.
-    // The LDS rows hold ACT_SCALE (P, Q), so z' = ACT_SCALE Swish(x) = x' / (1 + 2^(c x' / ACT_SCALE)) costs what Swish(x) did.
+    // ---- message_net_2 on Swish(P_i + Q_j): eight K = 16 steps u = 2 t + s; the matrix work of step u (12 MFMAs = 4 groups of 3)
+    // is interleaved with the activation of the same K step of the NEXT chunk (4 slices of two values), as in edge_tile_body.
     f32x16 y[4];
     {
         const float s2 = a.scales[1] * ACT_SCALE;
@@ -485,149 +487,140 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
                 for (int m = 0; m < 4; ++m) y[T][4 * q + m] = bv[m] * s2;
             }
     }
-    f32x4 pq[8];                 // P (0..3) and Q (4..7) pieces of the chunk being activated: channels 32 t + 8 q + 4 hh .. + 3
-    auto gather_tile = [&](int t) {
+    f32x4 pq[4];                 // P (0, 1) and Q (2, 3) pieces of the K step being activated: channels 32 t + 16 s + 8 j + 4 hh .. + 3
+    auto gather_step = [&](int t, int s) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            pq[q] = *reinterpret_cast<const f32x4*>(prow + 32 * t + 8 * q);
-            pq[4 + q] = *reinterpret_cast<const f32x4*>(qrow + 32 * t + 8 * q);
+        for (int j = 0; j < 2; ++j) {
+            pq[j] = *reinterpret_cast<const f32x4*>(prow + 32 * t + 16 * s + 8 * j);
+            pq[2 + j] = *reinterpret_cast<const f32x4*>(qrow + 32 * t + 16 * s + 8 * j);
         }
     };
-    // activation of two values (slice i = 0..7 of a chunk: piece q = i >> 1, elements 2 (i & 1), +1) into zt; written on float
-    // pairs so that the sums and products become packed instructions (v_pk_add_f32 / v_pk_mul_f32: two values per issue slot)
-    float zt[16];
-    auto act_slice = [&](int i) {
-        const int q = i >> 1, m0 = 2 * (i & 1);
+    float zt[8];
+    auto act_slice = [&](int i) {        // i = 0..3: piece j = i >> 1, elements 2 (i & 1), + 1
+        const int j = i >> 1, m0 = 2 * (i & 1);
 #if MSMP_PRECISE_ACT
-        for (int m = m0; m < m0 + 2; ++m) zt[4 * q + m] = ACT_SCALE * swishf((pq[q][m] + pq[4 + q][m]) * (1.0f / ACT_SCALE));
+        for (int m = m0; m < m0 + 2; ++m) zt[4 * j + m] = ACT_SCALE * swishf((pq[j][m] + pq[2 + j][m]) * (1.0f / ACT_SCALE));
 #else
-        const f32x2 x = f32x2{pq[q][m0], pq[q][m0 + 1]} + f32x2{pq[4 + q][m0], pq[4 + q][m0 + 1]};
+        const f32x2 x = f32x2{pq[j][m0], pq[j][m0 + 1]} + f32x2{pq[2 + j][m0], pq[2 + j][m0 + 1]};
         const f32x2 t = x * f32x2{-1.44269504088896340736f / ACT_SCALE, -1.44269504088896340736f / ACT_SCALE};
         const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
         const f32x2 z = x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-        zt[4 * q + m0] = z[0];
-        zt[4 * q + m0 + 1] = z[1];
+        zt[4 * j + m0] = z[0];
+        zt[4 * j + m0 + 1] = z[1];
 #endif
     };
-    half8 bhi[2][2], blo[2][2];      // [parity of the chunk][K = 16 step]: B fragments (acc order: registers 8 s .. 8 s + 7)
-    auto split_step = [&](int par, int s) {
-        float v[8];
+    half8 bhi[2], blo[2];          // [parity of the step]
+    gather_step(0, 0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = zt[8 * s + j];
-        split8(v, bhi[par][s], blo[par][s]);
-    };
-    gather_tile(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) act_slice(i);
-    split_step(0, 0);
-    split_step(0, 1);
-    gather_tile(1);
+    for (int i = 0; i < 4; ++i) act_slice(i);
+    split8(zt, bhi[0], blo[0]);
     TPROF(3);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int par = t & 1;
-        if (t < 3) wstage_load(ws, a.w2s + (size_t)(t + 1) * SPLIT_CHUNK_FLOATS, tid);
-        const half8* w = reinterpret_cast<const half8*>(wbuf + par * SPLIT_CHUNK_FLOATS) + lane;
-        // A fragments (hi, lo) of group g = (K step g >> 2, row tile g & 3): all 16 requested up front
-        half8 ahi[8], alo[8];
+    for (int u = 0; u < 8; ++u) {
+        const int par = u & 1;
+        if (u < 7) whalf_load(ws, a.w2s + (size_t)(u + 1) * WHALF_FLOATS, tid);
+        const half8* w = reinterpret_cast<const half8*>(wbuf + par * WHALF_FLOATS) + lane;
+        half8 ahi[4], alo[4];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            ahi[g] = w[(g * 2 + 0) * 64];
-            alo[g] = w[(g * 2 + 1) * 64];
+        for (int T = 0; T < 2; ++T) {
+            ahi[T] = w[(T * 2 + 0) * 64];
+            alo[T] = w[(T * 2 + 1) * 64];
+        }
+        if (u < 7) gather_step((u + 1) >> 1, (u + 1) & 1);
+#pragma unroll
+        for (int T = 2; T < 4; ++T) {
+            ahi[T] = w[(T * 2 + 0) * 64];
+            alo[T] = w[(T * 2 + 1) * 64];
         }
         TILE_SCHED_BARRIER();
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int s = g >> 2, T = g & 3;
-            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[g], bhi[par][s], y[T], 0, 0, 0);
-            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[g], blo[par][s], y[T], 0, 0, 0);
-            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[g], bhi[par][s], y[T], 0, 0, 0);
+        for (int T = 0; T < 4; ++T) {
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[T], bhi[par], y[T], 0, 0, 0);
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[T], blo[par], y[T], 0, 0, 0);
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[T], bhi[par], y[T], 0, 0, 0);
             TILE_SCHED_BARRIER();
-            if (t < 3) {
-                act_slice(g);
-                if (g == 3) split_step(par ^ 1, 0);
-                if (g == 7) split_step(par ^ 1, 1);
+            if (u < 7) {
+                act_slice(T);
+                if (T == 3) split8(zt, bhi[par ^ 1], blo[par ^ 1]);
                 TILE_SCHED_BARRIER();
             }
         }
-        if (t < 2) gather_tile(t + 2);          // P / Q pieces of the chunk after next: consumed in the next region
         TPROF(4);
-        if (t < 3) {
-            wstage_store_linear(ws, wbuf + (par ^ 1) * SPLIT_CHUNK_FLOATS, tid);
+        if (u < 7) {
+            whalf_store(ws, wbuf + (par ^ 1) * WHALF_FLOATS, tid);
             __syncthreads();
         }
         TPROF(5);
     }
 
-    // ---- mean over the in-edges of each target (same order of additions as scatter_mean_kernel: CSR order) -----------------
-    // Swish(y 2^-s2) = 2^-s2 y / (1 + 2^(c y)), c = -log2(e) 2^-s2: the power of two is applied once per node with the 1 / deg
-    // factor (exact, so the result is bit-identical to scaling every message first).
-    // One round: the staged messages [128 edges][128 channels] (row stride 132 floats) take the whole LDS (the W2 buffers and
-    // the P / Q rows are dead by now: 67.6 of the 70.6 KB).  Thread (node slot tid >> 5, channel group tid & 31) then sums the
-    // rows of nodes slot, slot + 8, ... in CSR order: up to 8 rows per node are read unconditionally (index clamped into the
-    // node's own rows) and accumulated with a 0 / 1 factor (fma(v, 1, s) = s + v and fma(v, 0, s) = s exactly, so the sum equals
-    // the sequential one bit for bit); longer rows loop.
+    // ---- mean over the in-edges of each target, CSR order, in two rounds of 64 staged edges ----------------------------------------
     constexpr int LDR = H + 4;
-    static_assert(TILE_EDGES * LDR <= TILE_LDS_FLOATS, "staged messages must fit the kernel's LDS");
-    const float inv2 = a.scales[5] * (1.0f / ACT_SCALE);        // the accumulators carry 2^s2 ACT_SCALE
+    const float inv2 = a.scales[5] * (1.0f / ACT_SCALE);
 #if MSMP_PRECISE_ACT
     const float post = 1.0f;
 #else
     const float cexp = -1.44269504088896340736f * inv2;
     const float post = inv2;
 #endif
-    __syncthreads();     // readers of wbuf (W2 chunk 3) and of the P / Q rows are done
-    TPROF(6);
-    {
-        float* o = lds + (wave * 32 + c) * LDR + 4 * hh;
+    f32x4 sum[4];
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
+    for (int k = 0; k < 4; ++k) sum[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        TPROF(9);
+        __syncthreads();     // round 0: readers of the weight buffer and of the P / Q rows are done; round 1: the sums of round 0 are taken
+        TPROF(6);
+        if ((wave >> 1) == rnd) {
+            float* o = lds + ((wave & 1) * 32 + c) * LDR + 4 * hh;
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
 #if MSMP_PRECISE_ACT
 #pragma unroll
-                for (int m = 0; m < 4; ++m) v[m] = swishf(y[T][4 * q + m] * inv2);
+                    for (int m = 0; m < 4; ++m) v[m] = swishf(y[T][4 * q + m] * inv2);
 #else
 #pragma unroll
-                for (int m = 0; m < 4; m += 2) {
-                    const f32x2 yy = {y[T][4 * q + m], y[T][4 * q + m + 1]};
-                    const f32x2 t = yy * f32x2{cexp, cexp};
-                    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
-                    const f32x2 z = yy * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-                    v[m] = z[0];
-                    v[m + 1] = z[1];
-                }
+                    for (int m = 0; m < 4; m += 2) {
+                        const f32x2 yy = {y[T][4 * q + m], y[T][4 * q + m + 1]};
+                        const f32x2 t = yy * f32x2{cexp, cexp};
+                        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+                        const f32x2 z = yy * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                        v[m] = z[0];
+                        v[m + 1] = z[1];
+                    }
 #endif
-                *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = v;
+                    *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = v;
+                }
+        }
+        TPROF(7);
+        __syncthreads();
+        TPROF(8);
+        const int lo_e = 64 * rnd, hi_e = 64 * rnd + 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r0 = max(r0b[k], lo_e), r1 = min(r1b[k], hi_e);       // this round's part of the node's rows (empty for nodes beyond the tile)
+            for (int rb = r0; rb < r1; rb += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(lds + (min(rb + i, r1 - 1) - lo_e) * LDR + 4 * cq);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float m = rb + i < r1 ? 1.0f : 0.0f;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) sum[k][x] = __builtin_fmaf(v[i][x], m, sum[k][x]);
+                }
             }
+        }
     }
-    TPROF(7);
-    __syncthreads();
-    TPROF(8);
-#pragma unroll 1
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int node = tile_n0 + nslot + 8 * k;
         if (node < tile_n1) {
-            const int r0 = k == 0 ? r0b[0] : k == 1 ? r0b[1] : k == 2 ? r0b[2] : r0b[3];
-            const int r1 = k == 0 ? r1b[0] : k == 1 ? r1b[1] : k == 2 ? r1b[2] : r1b[3];
-            const int deg = r1 - r0;
-            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-            if (deg > 0) {
-                for (int rb = r0; rb < r1; rb += 8) {
-                    f32x4 v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(lds + min(rb + i, r1 - 1) * LDR + 4 * cq);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float m = rb + i < r1 ? 1.0f : 0.0f;
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) sum[x] = __builtin_fmaf(v[i][x], m, sum[x]);
-                    }
-                }
-            }
+            const int deg = r1b[k] - r0b[k];
             const float invd = 1.0f / (float)max(deg, 1);
-            *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + 4 * cq) = (sum * post) * invd;
+            *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + 4 * cq) = (sum[k] * post) * invd;
         }
     }
     TPROF(9);
@@ -635,7 +628,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void edge_tile_kernel(TileArgs a, int n_tiles) {
+__global__ __launch_bounds__(256, 3) void edge_tile_kernel(TileArgs a, int n_tiles) {
     __shared__ __attribute__((aligned(16))) float lds[TILE_LDS_FLOATS];
     edge_tile_body<MODE>(a, lds, n_tiles);
 }
@@ -646,7 +639,7 @@ struct TileArgs2 {
     TileArgs head[2];
 };
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void edge_tile_pair_kernel(TileArgs2 a, int n_tiles) {
+__global__ __launch_bounds__(256, 3) void edge_tile_pair_kernel(TileArgs2 a, int n_tiles) {
     __shared__ __attribute__((aligned(16))) float lds[TILE_LDS_FLOATS];
     edge_tile_body<MODE>(a.head[blockIdx.y], lds, n_tiles);
 }

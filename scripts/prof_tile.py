@@ -25,9 +25,9 @@ _lib.check(L.msmp_node_project_f32(ptr(h), ptr(u), ptr(pos), ptr(var), n, 25, 2,
 tiles = gs.tiles(); tb = ctypes.byref(tiles[0])
 from msmp_pde_amd.layers import node_features
 FEAT = node_features(u, pos, var)
-names = ['prologue: index + row loads, staging, barrier', 'projection MFMAs (fold)', 'P/Q to LDS + barriers (fold)', 'first activation chunk + gathers',
-         'chunk: MFMAs + activation of next (x4)', 'chunk: weight store + barrier (x4)', 'epilogue barrier A (x2)', 'epilogue swish + stage (x2)',
-         'epilogue barrier B (x2)', 'segmented mean + store (x2)']
+names = ['prologue: index + row loads, staging, barrier', 'projection MFMAs (fold)', 'barrier, P/Q to LDS, barrier (fold)', 'first activation step + gathers',
+         'K = 16 step: MFMAs + activation of next (x8)', 'step: weight store + barrier (x7)', 'epilogue barrier A (x2)', 'epilogue swish + stage (x2, two waves each)',
+         'epilogue barrier B (x2)', 'segmented mean (x2) + store']
 for fold in (False, True):
     args = (ptr(h), ptr(u), ptr(pos), ptr(var), ptr(FEAT), None, None) if fold else (None, None, None, None, None, ptr(P), ptr(Q))
     run = lambda: _lib.check(L.msmp_edge_aggregate_tiled_f32(*args, ptr(gs.rowptr), tb, n, e, 25, 2, ptr(packed), ptr(agg), cs()), 'tiled')
@@ -38,7 +38,7 @@ for fold in (False, True):
     buf = (ctypes.c_ulonglong * 16)()
     L.msmp_debug_prof_tile(buf, 0)
     tot = sum(buf[i] for i in range(10)) or 1
-    n_wg = 5 * tiles[0].n_tiles
+    n_wg = buf[15] or 1        # workgroups that reported (one in 64)
     print(f'edge_tile_kernel<fold={fold}>: {tot / n_wg:.0f} cycles per workgroup (wave 0)')
     for i, nm in enumerate(names):
         print(f'  {nm:48s} {100.0 * buf[i] / tot:5.1f} %   {buf[i] / n_wg:8.0f} cycles')
