@@ -91,7 +91,7 @@ __device__ unsigned long long g_prof[16];
 #define PROF_ARGS , long long& tp, long long (&pacc)[12]
 #define PROF_PASS , tp, pacc
 #define PROF_MARK(i) do { const long long t_ = __builtin_readcyclecounter(); pacc[i] += t_ - tp; tp = t_; } while (0)
-#define PROF_FLUSH if (tid == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_prof[i_], (unsigned long long)pacc[i_]);
+#define PROF_FLUSH if (tid == 0 && (blockIdx.x & 15) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_prof[i_], (unsigned long long)pacc[i_]); atomicAdd(&g_prof[15], 1ull); }   /* one workgroup in 16 reports: see tile_kernels.hip */
 #if MSMP_PROF_EDGE
 #define PROF_EDGE(i) PROF_MARK(i)
 #define PROF_EDGE_FLUSH PROF_FLUSH

@@ -1,5 +1,6 @@
 import sys, ctypes
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import msmp_pde_amd as mp
 from msmp_pde_amd.synthetic import make_case, EXPERIMENTS
@@ -16,6 +17,8 @@ with torch.no_grad():
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 16)()
     L.msmp_debug_prof(buf, 0)
-    n = 3 * 6 * 2048
+    n = buf[15] or 1        # workgroups that reported (one in 16)
     names = ['gate head rest (GEMM4)', 'gate norm+sigmoid', 'main head rest', 'main norm', 'blend+store', 'head prologue (x2)', 'chunk: split+rowload (x16)', 'chunk: mma (x16)', 'chunk: weight wait+store (x16)', 'chunk: barrier (x16)', 'swish z (x2)']
-    for i, nm in enumerate(names): print(f'{nm:24s} {buf[i] / n:10.0f} cycles per workgroup')
+    tot = sum(buf[i] for i in range(11))
+    print(f'node_tail_split_kernel: {tot / n:.0f} cycles per workgroup (wave 0)')
+    for i, nm in enumerate(names): print(f'  {nm:32s} {buf[i] / n:10.0f} cycles  {100.0 * buf[i] / tot:5.1f} %')
