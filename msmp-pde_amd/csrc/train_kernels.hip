@@ -186,85 +186,174 @@ extern "C" int msmp_gate_blend_bwd_f32(const float* grad_out, const float* h, co
 // Weight gradients:  dW[m][n] = sum_r A[r][m] B[r][n]  and  db[m] = sum_r A[r][m]  for up to 8 (A, B) pairs in one call
 // (A [R,128] (row stride lda) = gradient of a pre-activation, B [R, >= k2] = the input of that linear layer, R = E or N rows).
 // These GEMMs are 128 x k2 outputs with a reduction over R >> 1000 rows: the library runs them on 36 workgroups
-// (63 us each at R = 9 408); here the rows are split over workgroups (<= 512 splits per pair; exact-fp32 MFMA partial products, the bias column
-// as a virtual all-ones column k2 of B), and a second kernel sums the partials in a fixed order (deterministic).
+// (63 us each at R = 9 408); here the rows are split over workgroups (<= 512 splits per pair; fp32 products from six bf16 MFMAs,
+// see split_bf16x3; the bias column as a virtual all-ones column k2 of B), and a second kernel sums the partials in a fixed order
+// (deterministic).
 // ----------------------------------------------------------------------------------------------
 namespace msmp {
 
 constexpr int GW_MAX_JOBS = 8;
+constexpr int GW_MAX_UNITS = 2 * GW_MAX_JOBS;       // a job of more than 160 columns is two column groups
 struct GradWeightJob {
     const float* a;      // [rows, lda], columns 0..127 used
     const float* b;      // [rows, ldb], columns 0..k2-1 used
     float* out_w;        // [128, k2]
     float* out_b;        // [128]
-    float* partial;      // [splits][128][32 * nt]
-    int rows, lda, ldb, k2, nt, rows_per_split, splits, first_block;
+    float* partial;      // [splits][128][ldp]
+    int rows, lda, ldb, k2, ldp, rows_per_split, splits, first_block;
+    int c0;              // first column of B of this unit's group (0 or 160)
 };
 struct GradWeightArgs {
-    GradWeightJob job[GW_MAX_JOBS];
-    int n_jobs;
+    GradWeightJob job[GW_MAX_JOBS];       // the reduction's view: one entry per job
+    GradWeightJob unit[GW_MAX_UNITS];     // the product kernel's view: one entry per (job, column group)
+    int n_jobs, n_units;
 };
 
-template <int NT>
+// fp32 products on the bf16 matrix pipe: x = hi + mid + lo EXACTLY with three truncated 8-bit pieces (bf16 has fp32's exponent
+// range, so gradients of any magnitude survive -- the fp16 split of the inference kernels would need a per-tensor scale), and
+//   a b = hi hi + (hi mid + mid hi) + (mid mid + hi lo + lo hi) + O(2^-24 a b):  six MFMAs per K = 16 step, fp32 accumulation.
+// 6 x 32 cycles per 16 rows against 8 x 64 for v_mfma_f32_32x32x2_f32: the matrix time drops 2.7x and the kernel becomes what it
+// should be, bound by reading A and B once (round 2; the exact-fp32 edition ran at 30 % of the fp32 MFMA peak, 9.4 ms per
+// batch-512 iteration).
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+struct Bf3 {
+    bf16x8 hi, mid, lo;
+};
+__device__ __forceinline__ Bf3 split_bf16x3(const float (&x)[8]) {
+    u32x4 h, m, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned hb[2], mb[2], lb[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float v = x[2 * i + k];
+            hb[k] = __float_as_uint(v) & 0xffff0000u;
+            const float r1 = v - __uint_as_float(hb[k]);              // exact
+            mb[k] = __float_as_uint(r1) & 0xffff0000u;
+            lb[k] = __float_as_uint(r1 - __uint_as_float(mb[k]));     // exact; its top 16 bits are taken by the permute below
+        }
+        h[i] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);      // {x1.b3, x1.b2, x0.b3, x0.b2}: two bf16 per register
+        m[i] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
+        l[i] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
+    }
+    return Bf3{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, m), __builtin_bit_cast(bf16x8, l)};
+}
+
+// One workgroup = one row split of one job's column group (<= 5 output tiles = 160 columns of B; jobs with more columns are cut
+// into groups so that the accumulators (80 registers) leave room for TWO 16-row blocks of operands in flight (96 registers): the
+// loop is bound by load latency otherwise (measured: a 9-tile body with one block in flight ran 2.6x SLOWER than the fp32-MFMA
+// kernel it replaced, ten dependent memory round trips per block).
+constexpr int GW_NT = 5;
+struct GwBlock {
+    float a[8];
+    float b[GW_NT][8];
+};
+// rows rbase .. rbase + 7 of this lane's column of A and of every tile's column of B; `rlim` = number of valid rows from rbase on
+// (>= 8 on the fast path: no row predicate at all)
+template <bool FULL>
+__device__ __forceinline__ void gw_load(const GradWeightJob& j, const float* acol, const float* const (&bcol)[GW_NT], int rbase, int rlim, GwBlock& blk) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = FULL ? rbase + i : rbase + min(i, max(rlim - 1, 0));
+        const float v = acol[(size_t)r * j.lda];
+        blk.a[i] = FULL || i < rlim ? v : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < GW_NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = FULL ? rbase + i : rbase + min(i, max(rlim - 1, 0));
+            const float v = bcol[t][(size_t)r * j.ldb];
+            blk.b[t][i] = FULL || i < rlim ? v : 0.f;
+        }
+}
+__device__ __forceinline__ void gw_compute(const GwBlock& blk, const float (&keep)[GW_NT], const float (&ones)[GW_NT], f32x16 (&acc)[GW_NT]) {
+    const Bf3 a3 = split_bf16x3(blk.a);
+#pragma unroll
+    for (int t = 0; t < GW_NT; ++t) {
+        float bv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bv[i] = fmaf(blk.b[t][i], keep[t], ones[t]);      // column past k2: 0; the bias column k2: 1
+        const Bf3 b3 = split_bf16x3(bv);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.lo, b3.hi, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.hi, b3.lo, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.mid, b3.mid, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.mid, b3.hi, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.hi, b3.mid, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.hi, b3.hi, acc[t], 0, 0, 0);
+    }
+}
+
 __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int split, int wave, int lane) {
     const int m = lane & 31, kk = lane >> 5;
-    f32x16 acc[NT];
+    f32x16 acc[GW_NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < GW_NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int r0 = split * j.rows_per_split, r1 = min(r0 + j.rows_per_split, j.rows);
-    // 4 k-steps (8 rows) per iteration with all 4 (1 + NT) loads issued before the first MFMA: the loop is bound by load
-    // latency otherwise.  Every lane runs the same trip count; rows past r1 are clamped and contribute 0.
-    constexpr int U = 4;
-    for (int rb = r0; rb < r1; rb += 2 * U) {
-        float av[U], bv[U][NT];
+    // lane (m, kk) holds rows rb + 8 kk .. + 7 of column 32 wave + m of A (the MFMA's A operand: 8 consecutive k per lane) and of
+    // column c0 + 32 t + m of B for each of the group's tiles; every load is a 128-byte row segment across the 32 lanes.
+    const float* acol = j.a + 32 * wave + m;
+    const float* bcol[GW_NT];
+    float keep[GW_NT], ones[GW_NT];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = rb + 2 * u + kk;
-            const bool in = r < r1;
-            const int rc = in ? r : r1 - 1;
-            av[u] = j.a[(size_t)rc * j.lda + 32 * wave + m];
-            av[u] = in ? av[u] : 0.f;
-            const float* brow = j.b + (size_t)rc * j.ldb;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int c = 32 * t + m;
-                const int cc = c < j.k2 ? c : 0;
-                const float b = brow[cc];
-                bv[u][t] = c < j.k2 ? b : (c == j.k2 ? 1.0f : 0.f);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+    for (int t = 0; t < GW_NT; ++t) {
+        const int c = j.c0 + 32 * t + m;
+        bcol[t] = j.b + (c < j.k2 ? c : 0);
+        keep[t] = c < j.k2 ? 1.0f : 0.f;
+        ones[t] = c == j.k2 ? 1.0f : 0.f;
     }
-    float* p = j.partial + (size_t)split * H * (32 * NT);
+    const int n_full = (r1 - r0) / 16;                   // whole 16-row blocks; a ragged rest takes the predicated path once
+    GwBlock b0, b1;
+    int rb = r0;
+    // the scheduling barriers pin "all loads of the NEXT block, then the whole matrix work of the current one": left alone the
+    // compiler sinks the loads next to their uses (fewer live registers) and the loop waits for memory ten times per block
+    if (n_full > 0) gw_load<true>(j, acol, bcol, rb + 8 * kk, 8, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    int k = 0;
+    for (; k + 2 <= n_full; k += 2) {
+        gw_load<true>(j, acol, bcol, rb + 16 + 8 * kk, 8, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        gw_compute(b0, keep, ones, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 2 < n_full) gw_load<true>(j, acol, bcol, rb + 32 + 8 * kk, 8, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        gw_compute(b1, keep, ones, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        rb += 32;
+    }
+    if (k < n_full) {                                    // one full block left (loaded into b0)
+        gw_compute(b0, keep, ones, acc);
+        rb += 16;
+    }
+    if (rb < r1) {
+        const int rlim = r1 - (rb + 8 * kk);              // valid rows of this lane's half block (may be <= 0)
+        gw_load<false>(j, acol, bcol, min(rb + 8 * kk, r1 - 1), rlim, b0);
+        gw_compute(b0, keep, ones, acc);
+    }
+    float* p = j.partial + (size_t)split * H * j.ldp + j.c0;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < GW_NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p[(size_t)(32 * wave + acc_row(r, kk)) * (32 * NT) + 32 * t + m] = acc[t][r];
+        for (int r = 0; r < 16; ++r)
+            if (j.c0 + 32 * t < j.ldp) p[(size_t)(32 * wave + acc_row(r, kk)) * j.ldp + 32 * t + m] = acc[t][r];
 }
 
-__global__ __launch_bounds__(256) void grad_weight_kernel(GradWeightArgs a) {
+__global__ __launch_bounds__(256, 2) void grad_weight_kernel(GradWeightArgs a) {
     int ji = 0;
 #pragma unroll
-    for (int i = 1; i < GW_MAX_JOBS; ++i)
-        if (i < a.n_jobs && (int)blockIdx.x >= a.job[i].first_block) ji = i;
-    const GradWeightJob& j = a.job[ji];
-    const int split = blockIdx.x - j.first_block, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    switch (j.nt) {
-        case 5: grad_weight_body<5>(j, split, wave, lane); break;
-        case 9: grad_weight_body<9>(j, split, wave, lane); break;
-        default: grad_weight_body<10>(j, split, wave, lane); break;
-    }
+    for (int i = 1; i < GW_MAX_UNITS; ++i)
+        if (i < a.n_units && (int)blockIdx.x >= a.unit[i].first_block) ji = i;
+    const GradWeightJob& j = a.unit[ji];
+    grad_weight_body(j, blockIdx.x - j.first_block, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
 // out[row][col] = sum over splits, in split order; grid.y = job
 __global__ __launch_bounds__(256) void grad_weight_reduce_kernel(GradWeightArgs a) {
     const GradWeightJob& j = a.job[blockIdx.y];
-    const int w = j.k2 + 1, ldp = 32 * j.nt, total = H * w;
+    const int w = j.k2 + 1, ldp = j.ldp, total = H * w;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
         const int row = p / w, c = p - row * w;
         const float* src = j.partial + (size_t)row * ldp + c;
@@ -307,7 +396,7 @@ static int launch_grad_weights(int n_jobs, const float* const* a, const float* c
     GradWeightArgs args;
     args.n_jobs = n_jobs;
     int64_t used = 0;
-    int blocks = 0, max_w = 0;
+    int blocks = 0, max_w = 0, nu = 0;
     for (int i = 0; i < n_jobs; ++i) {
         MSMP_REQUIRE(a[i] && b[i] && out_w[i] && out_b[i], MSMP_ERR_ARG, "msmp_grad_weights_f32: null pointer in job %d", i);
         MSMP_REQUIRE(rows[i] >= 1 && rows[i] < (1L << 31) && k2[i] >= 1 && ldb[i] >= k2[i] && lda[i] >= H, MSMP_ERR_ARG, "msmp_grad_weights_f32: bad sizes in job %d", i);
@@ -315,15 +404,21 @@ static int launch_grad_weights(int n_jobs, const float* const* a, const float* c
         MSMP_REQUIRE(nt > 0, MSMP_ERR_UNSUPPORTED, "msmp_grad_weights_f32: k2=%d > 319", k2[i]);
         GradWeightJob& j = args.job[i];
         j.a = a[i]; j.b = b[i]; j.out_w = out_w[i]; j.out_b = out_b[i]; j.partial = workspace + used;
-        j.rows = (int)rows[i]; j.lda = lda[i]; j.ldb = ldb[i]; j.k2 = k2[i]; j.nt = nt;
+        j.rows = (int)rows[i]; j.lda = lda[i]; j.ldb = ldb[i]; j.k2 = k2[i]; j.ldp = 32 * nt;
         j.rows_per_split = gw_rows_per_split(rows[i]);
         j.splits = (j.rows + j.rows_per_split - 1) / j.rows_per_split;
-        j.first_block = blocks;
-        blocks += j.splits;
+        j.first_block = 0; j.c0 = 0;
+        for (int c0 = 0; c0 < 32 * nt; c0 += 32 * GW_NT) {
+            GradWeightJob& u = args.unit[nu++];
+            u = j; u.c0 = c0; u.first_block = blocks;
+            blocks += j.splits;
+        }
         used += (int64_t)j.splits * H * 32 * nt;
         max_w = k2[i] + 1 > max_w ? k2[i] + 1 : max_w;
     }
+    args.n_units = nu;
     for (int i = n_jobs; i < GW_MAX_JOBS; ++i) args.job[i] = args.job[0];
+    for (int i = nu; i < GW_MAX_UNITS; ++i) args.unit[i] = args.unit[0];
     MSMP_REQUIRE(used <= workspace_floats, MSMP_ERR_WORKSPACE, "msmp_grad_weights_f32: workspace of %ld floats, need %ld", (long)workspace_floats, (long)used);
     hipLaunchKernelGGL(grad_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, args);
     hipLaunchKernelGGL(grad_weight_reduce_kernel, dim3((unsigned)((H * max_w + 255) / 256), (unsigned)n_jobs), dim3(256), 0, stream, args);

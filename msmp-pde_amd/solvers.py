@@ -32,26 +32,55 @@ def _lin(i, o):
     return nn.Linear(i, o, dtype=torch.float32)
 
 
+_TOEPLITZ = {}
+
+
+def _conv1d_as_matmul(x, weight, bias, stride):
+    """Conv1d(x [N, Cin, Lin]; weight [Cout, Cin, k], stride) as ONE dense GEMM [N, Cin Lin] x T [Cin Lin, Cout Lout], T the
+    convolution's Toeplitz matrix, itself a fixed 0/1 selection matrix times the flattened `weight` (differentiable both ways as GEMVs).
+    The decoder's convolutions have 1-2 input and 8 output channels: as unfold + einsum they are [N L, 16] x [16, 8] products for
+    which the library picked a 32x16-tile kernel (3.7 ms of a 48-ms training iteration at batch 512, plus the unfold backward);
+    as Toeplitz products they are [N,128] x [128,304] and [N,304] x [304,25]: well-shaped GEMMs forward and backward."""
+    cout, cin, k = weight.shape
+    n, _, lin = x.shape
+    lout = (lin - k) // stride + 1
+    key = (cout, cin, k, lin, stride, x.device, weight.dtype)
+    if key not in _TOEPLITZ:
+        i = torch.arange(lin, device=x.device)[:, None] - stride * torch.arange(lout, device=x.device)[None, :]      # tap index, [Lin, Lout]
+        valid = (i >= 0) & (i < k)
+        tap = i.clamp(0, k - 1)
+        ci = torch.arange(cin, device=x.device)[:, None, None, None]
+        co = torch.arange(cout, device=x.device)[None, None, :, None]
+        idx = ((co * cin + ci) * k + tap[None, :, None, :]).reshape(-1)                                                 # [Cin Lin Cout Lout]
+        mask = valid[None, :, None, :].expand(cin, lin, cout, lout).reshape(-1)
+        # selection matrix S [Cin Lin Cout Lout, Cout Cin k] with T = S w: a GEMV forward and backward (a gather's backward would be a
+        # sorted index_put: milliseconds at these sizes)
+        sel = torch.zeros(idx.numel(), cout * cin * k, dtype=weight.dtype, device=x.device)
+        rows = torch.nonzero(mask).reshape(-1)
+        sel[rows, idx[rows]] = 1
+        _TOEPLITZ[key] = sel
+    t = (_TOEPLITZ[key] @ weight.reshape(-1)).view(cin * lin, cout * lout)
+    out = x.reshape(n, cin * lin) @ t
+    return out.view(n, cout, lout) + bias[None, :, None]
+
+
 def _decoder_autograd(x, conv1, conv2):
-    """output_mlp (Conv1d -> Swish -> Conv1d) for the AUTOGRAD path, written with unfold + einsum so that the backward
-    is plain GEMM / elementwise work: MIOpen's implicit-GEMM backward-data kernel for this shape faulted on MI355X
+    """output_mlp (Conv1d -> Swish -> Conv1d) for the AUTOGRAD path, written as two Toeplitz GEMMs so that the backward is plain
+    GEMM / elementwise work: MIOpen's implicit-GEMM backward-data kernel for this shape faulted on MI355X
     (memory access fault inside igemm_bwd_gtcx35_nhwc_fp32, seen with rocgdb).  x [N, Cin, 128] -> [N, Cout, tw]."""
-    w = x.unfold(2, conv1.kernel_size[0], conv1.stride[0])                          # [N, Cin, L1, k1]
-    mid = torch.einsum('nilk,cik->ncl', w, conv1.weight) + conv1.bias[None, :, None]
+    mid = _conv1d_as_matmul(x, conv1.weight, conv1.bias, conv1.stride[0])
     mid = mid * torch.sigmoid(mid)
-    w2 = mid.unfold(2, conv2.kernel_size[0], 1)                                     # [N, 8, tw, k2]
-    return torch.einsum('nctk,ock->not', w2, conv2.weight) + conv2.bias[None, :, None]
+    return _conv1d_as_matmul(mid, conv2.weight, conv2.bias, 1)
 
 
 class _Conv1dNoMIOpen(nn.Conv1d):
-    """nn.Conv1d (same parameters and state_dict keys: `weight`, `bias`) whose forward is unfold + einsum.  Under autograd the
+    """nn.Conv1d (same parameters and state_dict keys: `weight`, `bias`) whose forward is a Toeplitz GEMM.  Under autograd the
     library path of these decoder shapes ([N, C, 128], kernel 16 / stride 3 and [N, 8, 38], kernel 14) reaches MIOpen's
     implicit-GEMM backward-data kernel, which faulted on MI355X (igemm_bwd_gtcx35_nhwc_fp32, round 1); `model.output_mlp(x)`
     called the reference's way therefore never dispatches a MIOpen convolution, forward or backward."""
 
     def forward(self, x):
-        w = x.unfold(2, self.kernel_size[0], self.stride[0])                         # [N, Cin, L, k]
-        return torch.einsum('nilk,cik->ncl', w, self.weight) + self.bias[None, :, None]
+        return _conv1d_as_matmul(x, self.weight, self.bias, self.stride[0])
 
 
 class _OutEdgeMean(torch.autograd.Function):

@@ -19,7 +19,7 @@ for name, lem_kernels in variants:
         opt = (torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-8, fused=True) if TORCH_ADAMW
                else mp.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-8))
         steps = [60] * bsz
-        for _ in range(2): training_step(model, case.creator, case.u_super, case.x, case.variables, steps, 1, opt)
+        for _ in range(4): training_step(model, case.creator, case.u_super, case.x, case.variables, steps, 1, opt)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         n = 5
         for _ in range(n): loss = training_step(model, case.creator, case.u_super, case.x, case.variables, steps, 1, opt)
