@@ -1289,10 +1289,12 @@ static int g_pair = 1;       // gated pair: both heads' projection / message ker
 constexpr int64_t PAIR_MAX_NODES = 65536;     // measured (E2, ms per rollout step, per-head vs paired): 256 graphs 1.33 / 1.14, 512: 2.06 / 1.95, 1024: 3.63 / 3.65, 2048: 6.95 / 7.07
 static int g_tile_arith = 1;  // ranged tiles: slot -> node arithmetically (tile_halo) instead of through the node list
 static int g_tile = 2;       // node tiles (tile_kernels.hip): 2 fold the projections into the message kernel, 1 staged P / Q rows, 0 off
+static int g_bwd_gemm = 1;   // layer backward: row GEMMs on rows_gemm_kernel (bf16x3 MFMA, fused epilogues); 0: rocblas_sgemm + separate passes
 static int g_tail = 1;       // fused node tail (msmp_node_tail_f32) inside msmp_mp_layer_f32; msmp_tune("tail", 0) chains the pieces
 int msmp_tune_get(const char* key) {
     if (!strcmp(key, "split")) return g_split;
     if (!strcmp(key, "tail")) return g_tail;
+    if (!strcmp(key, "bwd_gemm")) return g_bwd_gemm;
     if (!strcmp(key, "pair")) return g_pair;
     if (!strcmp(key, "tile")) return g_tile;
     if (!strcmp(key, "tile_arith")) return g_tile_arith;
@@ -1303,6 +1305,7 @@ extern "C" int msmp_tune_query(const char* key) { return key ? msmp_tune_get(key
 
 extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "tail")) { g_tail = value; return MSMP_OK; }
+    if (key && !strcmp(key, "bwd_gemm")) { g_bwd_gemm = value; return MSMP_OK; }
     if (key && !strcmp(key, "pair")) { g_pair = value; return MSMP_OK; }
     if (key && !strcmp(key, "tile")) { g_tile = value; return MSMP_OK; }
     if (key && !strcmp(key, "tile_arith")) { g_tile_arith = value; return MSMP_OK; }

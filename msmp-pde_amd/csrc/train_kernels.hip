@@ -616,26 +616,241 @@ static void carve(float*& p, long n, long e, int ld_e, int ld_n, HeadBuf& b) {
     b.upd = take((size_t)n * H); b.dupd = take((size_t)n * H); b.x3 = take((size_t)n * H); b.dcat_n = take((size_t)n * 2 * H);
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Row GEMMs of the layer backward on the bf16 matrix pipe (round 2; they were rocblas_sgemm calls at 27 % of the fp32 MFMA peak
+// plus separate bias / Swish / dSwish passes):   OUT[rows, 128] = epilogue( X[rows, K] W_eff^T ),  rows = E or N,  K <= 288.
+// Products are fp32-exact (split_bf16x3: six bf16 MFMAs per K = 16 step).  A workgroup owns 128 rows (wave w: rows 32 w .. + 31 as the
+// MFMA's A operand, a row per lane, its k slices loaded straight from the row); the weights come as pre-split fragments
+// (rg_pack_kernel, once per backward call) streamed through LDS in 24-KB chunks of 32 k.  The output tile is
+// [row][channel 4 c + T]: a lane owns four consecutive channels of 16 rows, so results, biases and the saved pre-activations of
+// the fused epilogues move as 16-byte pieces of 512-byte rows.
+//   EPI 0: a = acc + bias -> out0,  Swish(a) -> out1        (recompute of a hidden layer)
+//   EPI 1: acc + bias -> out0                                (recompute of an output layer)
+//   EPI 2: acc * Swish'(aux) -> out0                         (data gradient through a hidden layer)
+//   EPI 3: acc -> out0                                       (data gradient w.r.t. the layer input; 256 columns = two launches)
+// ----------------------------------------------------------------------------------------------------------------------
+constexpr int RG_CHUNK_U4 = 2 * 4 * 3 * 64;            // 16-byte fragments per 32-k chunk: [s][T][plane][lane]
+constexpr int RG_CHUNK_FLOATS = RG_CHUNK_U4 * 4;       // 24 KB
+
+struct RgPackJob {
+    const float* w;      // row-major, row stride ldw
+    u32x4* out;          // n_chunks * RG_CHUNK_U4 fragments
+    int ldw, K, n_chunks, col0, transposed;
+    // transposed = 0: W_eff[o][k] = w[(col0 + o) * ldw + k]   (forward form: rows of w are output channels)
+    // transposed = 1: W_eff[o][k] = w[k * ldw + col0 + o]     (data-gradient form: the reduction runs over w's rows)
+    int first_block;
+};
+constexpr int RG_MAX_PACK = 20;
+struct RgPackArgs {
+    RgPackJob job[RG_MAX_PACK];
+    int n_jobs;
+};
+__global__ __launch_bounds__(256) void rg_pack_kernel(RgPackArgs a) {
+    int ji = 0;
+    for (int i = 1; i < a.n_jobs; ++i)
+        if ((int)blockIdx.x >= a.job[i].first_block) ji = i;
+    const RgPackJob& j = a.job[ji];
+    const int id = (blockIdx.x - j.first_block) * 256 + threadIdx.x;      // ((chunk * 2 + s) * 4 + T) * 64 + lane
+    if (id >= j.n_chunks * 2 * 4 * 64) return;
+    const int lane = id & 63, T = (id >> 6) & 3, s = (id >> 8) & 1, chunk = id >> 9;
+    const int c = lane & 31, hh = lane >> 5, o = 4 * c + T, k0 = 32 * chunk + 16 * s + 8 * hh;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = k0 + i;
+        v[i] = k < j.K ? (j.transposed ? j.w[(size_t)k * j.ldw + j.col0 + o] : j.w[(size_t)(j.col0 + o) * j.ldw + k]) : 0.f;
+    }
+    const Bf3 f = split_bf16x3(v);
+    u32x4* dst = j.out + (size_t)(((chunk * 2 + s) * 4 + T) * 3) * 64 + lane;
+    dst[0] = __builtin_bit_cast(u32x4, f.hi);
+    dst[64] = __builtin_bit_cast(u32x4, f.mid);
+    dst[128] = __builtin_bit_cast(u32x4, f.lo);
+}
+
+struct RgArgs {
+    const float* x;      // [rows, ldx], columns 0..K-1 used (ldx a multiple of 4)
+    const u32x4* wfrag;  // n_chunks chunks from rg_pack_kernel
+    const float* bias;   // [128] (EPI 0, 1)
+    const float* aux;    // [rows, 128] saved pre-activation (EPI 2)
+    float* out0;         // [rows, ld0]
+    float* out1;         // [rows, 128] (EPI 0)
+    long rows;
+    int ldx, K, n_chunks, ld0;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RgArgs a) {
+    __shared__ __attribute__((aligned(16))) float wl[2 * RG_CHUNK_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const long row0 = (long)blockIdx.x * 128 + 32 * wave;
+    const long xr = min(row0 + c, a.rows - 1);
+    const float* xrow = a.x + (size_t)xr * a.ldx + 8 * hh;
+    // this lane's slices of its row for chunk ch: k = 32 ch + 16 s + 8 hh .. + 7; pieces past K read as 0 (K need not be a multiple of 4)
+    auto load_x = [&](int ch, f32x4 (&dst)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 32 * ch + 16 * (i >> 1) + 8 * hh + 4 * (i & 1);
+            if (k + 4 <= a.K) dst[i] = *reinterpret_cast<const f32x4*>(xrow + 32 * ch + 16 * (i >> 1) + 4 * (i & 1));
+            else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) dst[i][m] = k + m < a.K ? xrow[32 * ch + 16 * (i >> 1) + 4 * (i & 1) + m] : 0.f;
+            }
+        }
+    };
+    f32x4 wreg[6];
+    auto load_w = [&](int ch) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.wfrag) + (size_t)ch * RG_CHUNK_U4;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) wreg[i] = src[tid + 256 * i];
+    };
+    auto store_w = [&](int buf) {
+        f32x4* dst = reinterpret_cast<f32x4*>(wl + buf * RG_CHUNK_FLOATS);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dst[tid + 256 * i] = wreg[i];
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[T][r] = 0.f;
+    f32x4 xa[4], xb[4];
+    load_w(0);
+    load_x(0, xa);
+    store_w(0);
+    __syncthreads();
+    auto chunk_mma = [&](const f32x4 (&xv)[4], int buf) {
+        const u32x4* w = reinterpret_cast<const u32x4*>(wl + buf * RG_CHUNK_FLOATS) + lane;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float v[8] = {xv[2 * s][0], xv[2 * s][1], xv[2 * s][2], xv[2 * s][3], xv[2 * s + 1][0], xv[2 * s + 1][1], xv[2 * s + 1][2], xv[2 * s + 1][3]};
+            const Bf3 x3 = split_bf16x3(v);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                const u32x4* f = w + (size_t)((s * 4 + T) * 3) * 64;
+                const bf16x8 whi = __builtin_bit_cast(bf16x8, f[0]), wmid = __builtin_bit_cast(bf16x8, f[64]), wlo = __builtin_bit_cast(bf16x8, f[128]);
+                acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3.lo, whi, acc[T], 0, 0, 0);
+                acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3.hi, wlo, acc[T], 0, 0, 0);
+                acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3.mid, wmid, acc[T], 0, 0, 0);
+                acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3.mid, whi, acc[T], 0, 0, 0);
+                acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3.hi, wmid, acc[T], 0, 0, 0);
+                acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3.hi, whi, acc[T], 0, 0, 0);
+            }
+        }
+    };
+    for (int ch = 0; ch < a.n_chunks; ch += 2) {
+        if (ch + 1 < a.n_chunks) { load_w(ch + 1); load_x(ch + 1, xb); }
+        chunk_mma(xa, 0);
+        if (ch + 1 < a.n_chunks) {
+            store_w(1);
+            __syncthreads();
+            if (ch + 2 < a.n_chunks) { load_w(ch + 2); load_x(ch + 2, xa); }
+            chunk_mma(xb, 1);
+            if (ch + 2 < a.n_chunks) {
+                store_w(0);
+                __syncthreads();
+            }
+        }
+    }
+    // ---- epilogue: lane c holds channels 4 c .. 4 c + 3 (tiles T = 0..3) of rows row0 + acc_row(r, hh) -----------------------
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (EPI <= 1) bias4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * c);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long row = row0 + acc_row(r, hh);
+        if (row >= a.rows) continue;
+        f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        if (EPI <= 1) v += bias4;
+        if (EPI == 2) {
+            const f32x4 pre = *reinterpret_cast<const f32x4*>(a.aux + (size_t)row * H + 4 * c);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) v[m] *= dswish(pre[m]);
+        }
+        *reinterpret_cast<f32x4*>(a.out0 + (size_t)row * a.ld0 + 4 * c) = v;
+        if (EPI == 0) {
+            f32x4 sw;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sw[m] = swishf(v[m]);
+            *reinterpret_cast<f32x4*>(a.out1 + (size_t)row * H + 4 * c) = sw;
+        }
+    }
+}
+
+static int rows_gemm(int epi, const float* x, int ldx, long rows, int K, const u32x4* wfrag, const float* bias, const float* aux, float* out0,
+                     int ld0, float* out1, hipStream_t st) {
+    RgArgs a{x, wfrag, bias, aux, out0, out1, rows, ldx, K, (K + 31) / 32, ld0};
+    const dim3 grid((unsigned)((rows + 127) / 128));
+    switch (epi) {
+        case 0: hipLaunchKernelGGL(rows_gemm_kernel<0>, grid, dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL(rows_gemm_kernel<1>, grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(rows_gemm_kernel<2>, grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(rows_gemm_kernel<3>, grid, dim3(256), 0, st, a); break;
+    }
+    return check_launch("rows_gemm_kernel");
+}
+
+// the ten weight operands of one head, packed once per backward call
+struct HeadFrags {
+    u32x4 *w1, *w2, *w3, *w4;            // forward forms (K = kmsg, 128, kupd, 128)
+    u32x4 *w4t, *w3t[2], *w2t, *w1t[2];  // data-gradient forms (reduction over the 128 output channels; 128-column groups of the input)
+};
+static size_t head_frag_u4(int kmsg, int kupd) {
+    return (size_t)RG_CHUNK_U4 * ((kmsg + 31) / 32 + 4 + (kupd + 31) / 32 + 4 + 6 * 4);
+}
+static void carve_frags(u32x4*& p, int kmsg, int kupd, HeadFrags& f) {
+    auto take = [&](int chunks) { u32x4* r = p; p += (size_t)chunks * RG_CHUNK_U4; return r; };
+    f.w1 = take((kmsg + 31) / 32); f.w2 = take(4); f.w3 = take((kupd + 31) / 32); f.w4 = take(4);
+    f.w4t = take(4); f.w3t[0] = take(4); f.w3t[1] = take(4); f.w2t = take(4); f.w1t[0] = take(4); f.w1t[1] = take(4);
+}
+static void add_pack(RgPackArgs& a, int& blocks, const float* w, int ldw, int K, int col0, int transposed, u32x4* out) {
+    RgPackJob& j = a.job[a.n_jobs++];
+    j.w = w; j.out = out; j.ldw = ldw; j.K = K; j.n_chunks = (K + 31) / 32; j.col0 = col0; j.transposed = transposed; j.first_block = blocks;
+    blocks += (j.n_chunks * 512 + 255) / 256;
+}
+static int pack_head_frags(const float* const* p, int kmsg, int kupd, const HeadFrags& f, RgPackArgs& a, int& blocks) {
+    add_pack(a, blocks, p[0], kmsg, kmsg, 0, 0, f.w1);
+    add_pack(a, blocks, p[2], H, H, 0, 0, f.w2);
+    add_pack(a, blocks, p[4], kupd, kupd, 0, 0, f.w3);
+    add_pack(a, blocks, p[6], H, H, 0, 0, f.w4);
+    add_pack(a, blocks, p[6], H, H, 0, 1, f.w4t);
+    add_pack(a, blocks, p[4], kupd, H, 0, 1, f.w3t[0]);
+    add_pack(a, blocks, p[4], kupd, H, H, 1, f.w3t[1]);
+    add_pack(a, blocks, p[2], H, H, 0, 1, f.w2t);
+    add_pack(a, blocks, p[0], kmsg, H, 0, 1, f.w1t[0]);
+    add_pack(a, blocks, p[0], kmsg, H, H, 1, f.w1t[1]);
+    return MSMP_OK;
+}
+
 #define BLAS_OK(call, what) do { if ((call) != rocblas_status_success) { set_error("msmp_mp_layer_bwd_f32: rocblas_sgemm failed (%s)", what); return MSMP_ERR_HIP; } } while (0)
 #define RC(call) do { const int rc_ = (call); if (rc_) return rc_; } while (0)
 
 // upd = W4 Swish(W3 [h, mean_j Swish(W2 Swish(W1 cat_e + b1) + b2), vars] + b3) + b4, keeping the pre-activations
-static int head_recompute(const BwdCtx& c, Blas& bl, const float* const* p, HeadBuf& b, bool build_cat_e) {
+static int head_recompute(const BwdCtx& c, Blas& bl, const HeadFrags* fr, const float* const* p, HeadBuf& b, bool build_cat_e) {
     const long n = c.n, e = c.e;
     if (e) {
         if (build_cat_e) RC(msmp_edge_concat_f32(c.h, c.u, c.pos, c.vars, c.tgt, c.col, e, c.tw, c.nv, c.ld_e, b.cat_e, c.st));
-        BLAS_OK(gemm_nt(bl, (int)e, H, c.kmsg, b.cat_e, c.ld_e, p[0], c.kmsg, b.a1, H), "message_net_1");
-        hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.a1, p[1], b.m1, e * 32);
-        BLAS_OK(gemm_nt(bl, (int)e, H, H, b.m1, H, p[2], H, b.a2, H), "message_net_2");
-        hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.a2, p[3], b.x2, e * 32);
+        if (fr) {
+            RC(rows_gemm(0, b.cat_e, c.ld_e, e, c.kmsg, fr->w1, p[1], nullptr, b.a1, H, b.m1, c.st));
+            RC(rows_gemm(0, b.m1, H, e, H, fr->w2, p[3], nullptr, b.a2, H, b.x2, c.st));
+        } else {
+            BLAS_OK(gemm_nt(bl, (int)e, H, c.kmsg, b.cat_e, c.ld_e, p[0], c.kmsg, b.a1, H), "message_net_1");
+            hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.a1, p[1], b.m1, e * 32);
+            BLAS_OK(gemm_nt(bl, (int)e, H, H, b.m1, H, p[2], H, b.a2, H), "message_net_2");
+            hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.a2, p[3], b.x2, e * 32);
+        }
         RC(msmp_scatter_mean_f32(b.x2, c.rowptr, n, b.agg, c.st));
     } else
         hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n * H)), dim3(256), 0, c.st, b.agg, 0.f, n * H);
     hipLaunchKernelGGL(cat_node_kernel, dim3(grid_for(n * 64)), dim3(256), 0, c.st, c.h, b.agg, c.vars, n, c.nv, c.ld_n, b.cat_n);
-    BLAS_OK(gemm_nt(bl, (int)n, H, c.kupd, b.cat_n, c.ld_n, p[4], c.kupd, b.a3, H), "update_net_1");
-    hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, b.a3, p[5], b.u1, n * 32);
-    BLAS_OK(gemm_nt(bl, (int)n, H, H, b.u1, H, p[6], H, b.upd, H), "update_net_2");
-    hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, b.upd, p[7], (float*)nullptr, n * 32);
+    if (fr) {
+        RC(rows_gemm(0, b.cat_n, c.ld_n, n, c.kupd, fr->w3, p[5], nullptr, b.a3, H, b.u1, c.st));
+        RC(rows_gemm(1, b.u1, H, n, H, fr->w4, p[7], nullptr, b.upd, H, nullptr, c.st));
+    } else {
+        BLAS_OK(gemm_nt(bl, (int)n, H, c.kupd, b.cat_n, c.ld_n, p[4], c.kupd, b.a3, H), "update_net_1");
+        hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, b.a3, p[5], b.u1, n * 32);
+        BLAS_OK(gemm_nt(bl, (int)n, H, H, b.u1, H, p[6], H, b.upd, H), "update_net_2");
+        hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, b.upd, p[7], (float*)nullptr, n * 32);
+    }
     return check_launch("layer backward: recompute");
 }
 
@@ -651,17 +866,29 @@ struct GwJobs {
 };
 
 // b.dupd = dL/d upd  ->  dh += dL/dh through this head; the four (gradient, input) pairs are queued for the weight-gradient kernel
-static int head_backward(const BwdCtx& c, Blas& bl, const float* const* p, HeadBuf& b, float* dh, float* const* grads, GwJobs& jobs) {
+static int head_backward(const BwdCtx& c, Blas& bl, const HeadFrags* fr, const float* const* p, HeadBuf& b, float* dh, float* const* grads, GwJobs& jobs) {
     const long n = c.n, e = c.e;
-    BLAS_OK(gemm_nn(bl, (int)n, H, H, b.dupd, H, p[6], H, b.x3, H), "d update_net_2");
-    hipLaunchKernelGGL(dsilu_mul_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, b.x3, b.a3, b.x3, n * 32);                 // d a3
-    BLAS_OK(gemm_nn(bl, (int)n, 2 * H, H, b.x3, H, p[4], c.kupd, b.dcat_n, 2 * H), "d update_net_1");                            // [dh | dagg]
+    if (fr) {
+        RC(rows_gemm(2, b.dupd, H, n, H, fr->w4t, nullptr, b.a3, b.x3, H, nullptr, c.st));                                       // d a3
+        RC(rows_gemm(3, b.x3, H, n, H, fr->w3t[0], nullptr, nullptr, b.dcat_n, 2 * H, nullptr, c.st));                           // [dh |
+        RC(rows_gemm(3, b.x3, H, n, H, fr->w3t[1], nullptr, nullptr, b.dcat_n + H, 2 * H, nullptr, c.st));                       //  dagg]
+    } else {
+        BLAS_OK(gemm_nn(bl, (int)n, H, H, b.dupd, H, p[6], H, b.x3, H), "d update_net_2");
+        hipLaunchKernelGGL(dsilu_mul_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, b.x3, b.a3, b.x3, n * 32);             // d a3
+        BLAS_OK(gemm_nn(bl, (int)n, 2 * H, H, b.x3, H, p[4], c.kupd, b.dcat_n, 2 * H), "d update_net_1");                        // [dh | dagg]
+    }
     hipLaunchKernelGGL(add_cols_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, dh, b.dcat_n, 2 * H, n);
     if (e) {
         hipLaunchKernelGGL(mean_bwd_dswish_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.dcat_n + H, 2 * H, c.rowptr, c.tgt, b.a2, e, b.x2);   // d a2
-        BLAS_OK(gemm_nn(bl, (int)e, H, H, b.x2, H, p[2], H, b.x1, H), "d message_net_2");
-        hipLaunchKernelGGL(dsilu_mul_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.x1, b.a1, b.x1, e * 32);             // d a1
-        BLAS_OK(gemm_nn(bl, (int)e, 2 * H, H, b.x1, H, p[0], c.kmsg, b.dcat_e, 2 * H), "d message_net_1");                      // [d x_i | d x_j]
+        if (fr) {
+            RC(rows_gemm(2, b.x2, H, e, H, fr->w2t, nullptr, b.a1, b.x1, H, nullptr, c.st));                                     // d a1
+            RC(rows_gemm(3, b.x1, H, e, H, fr->w1t[0], nullptr, nullptr, b.dcat_e, 2 * H, nullptr, c.st));                       // [d x_i |
+            RC(rows_gemm(3, b.x1, H, e, H, fr->w1t[1], nullptr, nullptr, b.dcat_e + H, 2 * H, nullptr, c.st));                   //  d x_j]
+        } else {
+            BLAS_OK(gemm_nn(bl, (int)e, H, H, b.x2, H, p[2], H, b.x1, H), "d message_net_2");
+            hipLaunchKernelGGL(dsilu_mul_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.x1, b.a1, b.x1, e * 32);         // d a1
+            BLAS_OK(gemm_nn(bl, (int)e, 2 * H, H, b.x1, H, p[0], c.kmsg, b.dcat_e, 2 * H), "d message_net_1");                  // [d x_i | d x_j]
+        }
         hipLaunchKernelGGL(scatter_target_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.rowptr, n);
         if (c.src_rowptr)
             hipLaunchKernelGGL(scatter_source_sorted_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.src_rowptr,
@@ -699,7 +926,8 @@ extern "C" size_t msmp_mp_layer_bwd_workspace_bytes(int64_t n_nodes, int64_t n_e
     const int heads = gated ? 2 : 1;
     const int64_t gw = bwd_gw_floats(n_nodes, n_edges, kmsg, kupd, heads);
     if (gw < 0) return 0;
-    return (heads * (head_floats(n_nodes, n_edges, ld_e, ld_n) + 15 * 64) + (size_t)gw + 64) * sizeof(float) + 256;
+    return (heads * (head_floats(n_nodes, n_edges, ld_e, ld_n) + 15 * 64) + (size_t)gw + 64) * sizeof(float) + 256 +
+           heads * head_frag_u4(kmsg, kupd) * sizeof(u32x4) + 256;
 }
 
 extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, const float* u, const float* pos, const float* vars,
@@ -724,10 +952,17 @@ extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, cons
     }
     const size_t need = msmp_mp_layer_bwd_workspace_bytes(n_nodes, n_edges, tw, nv, gated);
     MSMP_REQUIRE(need && workspace_bytes >= need, MSMP_ERR_WORKSPACE, "msmp_mp_layer_bwd_f32: workspace %zu < %zu", workspace_bytes, need);
-    Blas& bl = blas();
-    MSMP_REQUIRE(bl.handle, MSMP_ERR_UNSUPPORTED, "msmp_mp_layer_bwd_f32: librocblas (rocblas_sgemm) is not available in this process");
+    // rows_gemm_kernel from 32 768 edges on (measured E2 MSMP-PDE, ms per training iteration, library / own: batch 16 5.6 / 6.5,
+    // batch 128 12.8 / 12.1, batch 512 39.0 / 34.0: below that the 128-row workgroups do not fill the chip); tune "bwd_gemm": 0 never, 2 always
+    const int bg_mode = msmp_tune_get("bwd_gemm");
+    const bool own_gemm = bg_mode == 2 || (bg_mode == 1 && n_edges >= 32768);
+    static Blas none;
+    Blas& bl = own_gemm ? none : blas();
     hipStream_t st = (hipStream_t)stream;
-    MSMP_REQUIRE(bl.set_stream(bl.handle, st) == rocblas_status_success, MSMP_ERR_HIP, "msmp_mp_layer_bwd_f32: rocblas_set_stream failed");
+    if (!own_gemm) {
+        MSMP_REQUIRE(bl.handle, MSMP_ERR_UNSUPPORTED, "msmp_mp_layer_bwd_f32: librocblas (rocblas_sgemm) is not available in this process");
+        MSMP_REQUIRE(bl.set_stream(bl.handle, st) == rocblas_status_success, MSMP_ERR_HIP, "msmp_mp_layer_bwd_f32: rocblas_set_stream failed");
+    }
 
     BwdCtx c{h, u, pos, vars, rowptr, col, tgt, graph_ptr, src_rowptr, src_perm, (long)n_nodes, (long)n_edges, (long)n_graphs, tw, nv,
              2 * H + tw + 1 + nv, 2 * H + nv, 0, 0, st};
@@ -741,23 +976,42 @@ extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, cons
     const int64_t gw_floats = bwd_gw_floats(c.n, c.e, c.kmsg, c.kupd, gated ? 2 : 1);
     const long n4 = c.n * 32;
     GwJobs jobs;
+    HeadFrags fm, fg;
+    const HeadFrags *frm = nullptr, *frg = nullptr;
+    if (own_gemm) {      // split the weights of the call's head(s) into bf16 fragments: one launch
+        u32x4* fp = reinterpret_cast<u32x4*>(((uintptr_t)(gw_ws + gw_floats + 64) + 255) & ~(uintptr_t)255);
+        RgPackArgs pa;
+        pa.n_jobs = 0;
+        int blocks = 0;
+        carve_frags(fp, c.kmsg, c.kupd, fm);
+        pack_head_frags(params_main, c.kmsg, c.kupd, fm, pa, blocks);
+        frm = &fm;
+        if (gated) {
+            carve_frags(fp, c.kmsg, c.kupd, fg);
+            pack_head_frags(params_gate, c.kmsg, c.kupd, fg, pa, blocks);
+            frg = &fg;
+        }
+        for (int i = pa.n_jobs; i < RG_MAX_PACK; ++i) pa.job[i] = pa.job[0];
+        hipLaunchKernelGGL(rg_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pa);
+        RC(check_launch("rg_pack_kernel"));
+    }
 
-    RC(head_recompute(c, bl, params_main, bm, true));
+    RC(head_recompute(c, bl, frm, params_main, bm, true));
     if (gated) {
         bg.cat_e = bm.cat_e;                      // both heads read the same per-edge input
-        RC(head_recompute(c, bl, params_gate, bg, false));
+        RC(head_recompute(c, bl, frg, params_gate, bg, false));
         RC(msmp_gate_blend_bwd_f32(grad_out, h, bg.upd, bm.upd, graph_ptr, n_graphs, eps, bg.dupd, bm.dupd, dh_out, stream));
-        RC(head_backward(c, bl, params_main, bm, dh_out, grads_main, jobs));
-        RC(head_backward(c, bl, params_gate, bg, dh_out, grads_gate, jobs));
+        RC(head_backward(c, bl, frm, params_main, bm, dh_out, grads_main, jobs));
+        RC(head_backward(c, bl, frg, params_gate, bg, dh_out, grads_gate, jobs));
     } else if (mode == MSMP_LAYER_LIN) {          // out = IN(upd): no direct path to h
         RC(msmp_instance_norm_bwd_f32(bm.upd, grad_out, graph_ptr, n_graphs, eps, bm.dupd, stream));
         hipLaunchKernelGGL(fill_kernel, dim3(grid_for(c.n * H)), dim3(256), 0, st, dh_out, 0.f, c.n * H);
-        RC(head_backward(c, bl, params_main, bm, dh_out, grads_main, jobs));
+        RC(head_backward(c, bl, frm, params_main, bm, dh_out, grads_main, jobs));
     } else {                                      // out = IN(h + Swish(upd))
         hipLaunchKernelGGL(residual_silu_kernel, dim3(grid_for(n4)), dim3(256), 0, st, h, bm.upd, bm.dcat_n, n4);
         RC(msmp_instance_norm_bwd_f32(bm.dcat_n, grad_out, graph_ptr, n_graphs, eps, dh_out, stream));
         hipLaunchKernelGGL(dsilu_mul_kernel, dim3(grid_for(n4)), dim3(256), 0, st, dh_out, bm.upd, bm.dupd, n4);
-        RC(head_backward(c, bl, params_main, bm, dh_out, grads_main, jobs));
+        RC(head_backward(c, bl, frm, params_main, bm, dh_out, grads_main, jobs));
     }
     return launch_grad_weights(jobs.n, jobs.a, jobs.b, jobs.rows, jobs.lda, jobs.ldb, jobs.k2, jobs.out_w, jobs.out_b, gw_ws, gw_floats, st);
 }
