@@ -275,9 +275,21 @@ def test_grad_weights_kernel_shapes_and_strides(mp):
         grad_weights([(pairs[0][0], torch.randn(1, 320).cuda())])              # k2 > 319
 
 
+@pytest.fixture(params=[0, 2], ids=['rocblas', 'own_gemm'])
+def bwd_gemm(request, mp):
+    """Both GEMM paths of msmp_mp_layer_bwd_f32 (tune "bwd_gemm": 0 = rocblas_sgemm + separate epilogues, 2 = rows_gemm_kernel; the
+    default picks by size, which at test sizes would always be the library)."""
+    from msmp_pde_amd._lib import check
+    L = mp.lib()
+    prev = L.msmp_tune_query(b'bwd_gemm')
+    check(L.msmp_tune(b'bwd_gemm', request.param), 'tune')
+    yield request.param
+    check(L.msmp_tune(b'bwd_gemm', prev), 'tune')
+
+
 @pytest.mark.parametrize('form', ['residual', 'lin', 'gated'])
 @pytest.mark.parametrize('n_edges', [0, 900])
-def test_layer_backward_entry_vs_float64_autograd(mp, form, n_edges):
+def test_layer_backward_entry_vs_float64_autograd(mp, form, n_edges, bwd_gemm):
     """msmp_mp_layer_bwd_f32 through the C-ABI on ragged graphs (1, 100, 3, 130, 2 nodes; nodes without in-edges; an edgeless
     batch): dL/dh and all parameter gradients against float64 torch.autograd over the restatement of the layer."""
     from msmp_pde_amd import autograd as A
