@@ -296,6 +296,28 @@ class _SolverBase(nn.Module):
         return out
 
     # -- forward -------------------------------------------------------------------------------
+    INPUT_RANGE = 255.0
+
+    def input_range(self, data):
+        """Largest |value| among the node features the kernels see (u, pos_x, the variables columns) -- one device reduction and a
+        host sync, so NOT part of forward(): call it once per dataset.  The default (fp16-split) matrix path carries node rows
+        scaled by 2^8 and saturates them at +-65504 (tile_kernels.hip), i.e. it needs |feature| <= 255 after the reference's own
+        normalisation (pos / L, variables / eq_variables): PDE data of order one.  Data outside that range must run on the exact-fp32
+        MFMA kernels: `msmp_pde_amd.lib().msmp_tune(b'split', 0)` (no range limit, ~2x slower)."""
+        prep = self._prepare(data, False)
+        if prep is None:
+            raise RuntimeError('input_range: device tensors of dtype float32 / float64 expected')
+        u, pos_x, _, variables, _ = prep
+        return float(max(u.abs().max(), pos_x.abs().max(), variables.abs().max()))
+
+    def validate_inputs(self, data):
+        """Raise if `data` is outside the range the default matrix path represents (see input_range)."""
+        r = self.input_range(data)
+        if not r <= self.INPUT_RANGE:
+            raise ValueError(f'node features reach |x| = {r:.4g} > {self.INPUT_RANGE:g}: the fp16-split matrix path would saturate them; '
+                             "rescale the data or select the exact-fp32 kernels with lib().msmp_tune(b'split', 0)")
+        return r
+
     def forward(self, data):
         u_in = data.x
         pos = data.pos

@@ -410,3 +410,38 @@ def test_state_saving_lem_rollout_vs_oracle(mp, kind, exp, kw):
     for name, p in model.named_parameters():
         e = (p.grad.double().cpu() - sd64[name].grad).abs().max().item()
         assert e < 2e-3 * sd64[name].grad.abs().max().item() + 1e-4 * scale, (name, e)
+
+
+@pytest.mark.gpu
+def test_input_range_guard_and_exact_fp32_fallback(mp):
+    """The default (fp16-split) matrix path carries node features scaled by 2^8 and saturates them at +-65504: it represents
+    |feature| <= 255.  `Solver.validate_inputs` reports data outside that range (one reduction, not part of forward), and the
+    documented fallback -- msmp_tune("split", 0), the exact-fp32 MFMA kernels -- evaluates such data: a solution offset by 1000
+    against the float64 oracle (the bar is loose on purpose: with |u| = 1000 the float32 INPUT already carries 6e-5 of rounding that
+    the layers' InstanceNorms amplify; the point is finite, un-saturated results)."""
+    from msmp_pde_amd.synthetic import make_case
+    from types import SimpleNamespace
+    torch.manual_seed(3)
+    c = make_case('E2', 3, seed=9, device='cuda', dtype=torch.float64)
+    steps = [50] * 3
+    data, labels = c.creator.create_data(c.u_super, steps)
+    graph = c.creator.create_graph(data, labels, c.x, c.variables, steps)
+    kind = 'MP_PDE_SolverLEMLinGated'
+    model = getattr(mp, kind)(c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=2).cuda().eval()
+    assert model.validate_inputs(graph) <= 255.0
+    graph.x = graph.x + 1000.0
+    assert abs(model.input_range(graph) - float(graph.x.abs().max())) < 1e-3
+    with pytest.raises(ValueError, match='split'):
+        model.validate_inputs(graph)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    g = SimpleNamespace(**{k: v.detach().cpu().numpy() for k, v in graph.__dict__.items() if torch.is_tensor(v)})
+    ref = O.solver_forward(kind, sd, g, c.pde, TW, c.eqv, 2)
+    mp.lib().msmp_tune(b'split', 0)
+    try:
+        with torch.no_grad():
+            out = model(graph)
+    finally:
+        mp.lib().msmp_tune(b'split', 1)
+    err = np.abs(out.double().cpu().numpy() - ref).max()
+    print(f'offset input (|u| ~ 1000) on the exact-fp32 kernels: max|hip - oracle| = {err:.3e} on outputs of magnitude {np.abs(ref).max():.4g}')
+    assert np.isfinite(out.cpu().numpy()).all() and err < 2e-3 * np.abs(ref).max()
