@@ -171,7 +171,7 @@ typedef struct {
     const int32_t* tile_halo;    /* [n_tiles][4]: (lo start, lo count, hi start, hi count) when the tile's sources outside it are one
                                   * run of consecutive nodes below and one above (slots then follow node order and the kernel needs
                                   * no list lookup); lo count = -1 otherwise */
-    const int32_t* edge_slot;    /* [E] per CSR edge: target slot | source slot << 8 */
+    const int32_t* edge_slot;    /* [n_tiles][MSMP_TILE_EDGES]: k-th in-edge of the tile (CSR order): target slot | source slot << 8; 0 past the tile's edges */
 } msmp_tiles_t;
 /* stats_out (device, 2 x int32): largest node list, largest edge count over the tiles (lists longer than MSMP_TILE_NCAP are
  * truncated in the output: the structure is then not usable with this tile_nodes). */

@@ -114,9 +114,10 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
         // target slot of edge e0 + k: the CSR row it lies in (rows of a tile are short: linear search over <= tile_nodes rows)
         int ts = 0;
         while (ts + 1 < nt && rowptr[n0 + ts + 1] <= e0 + k) ++ts;
-        edge_slot[e0 + k] = ts | (min(slot, 255) << 8);
+        edge_slot[(size_t)t * TILE_EDGES + k] = ts | (min(slot, 255) << 8);
         if (first && slot < TILE_NCAP) tile_node[(size_t)t * TILE_NCAP + slot] = j;
-    }
+    } else if (k < TILE_EDGES)
+        edge_slot[(size_t)t * TILE_EDGES + k] = 0;           // lanes past the tile's edges read a valid slot pair; their messages are never summed
     if (k < TILE_NCAP && k < nt) tile_node[(size_t)t * TILE_NCAP + k] = n0 + k;
     __syncthreads();
     if (k == 0) {
@@ -270,7 +271,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
     (void)n_tiles;
     const int tile_n0 = tile * a.tile_nodes;
     const int tile_n1 = (int)min((long)tile_n0 + a.tile_nodes, a.n_nodes);
-    const int tile_e0 = a.rowptr[tile_n0], tile_e1 = a.rowptr[tile_n1];
+    const int tile_e0 = a.rowptr[tile_n0];
     const int* tnode = a.tile_node + (size_t)tile * TILE_NCAP;
     int h_lo = 0, h_nlo = -1, h_hi = 0, h_nhi = 0;
     if (a.tile_halo) { h_lo = a.tile_halo[4 * tile]; h_nlo = a.tile_halo[4 * tile + 1]; h_hi = a.tile_halo[4 * tile + 2]; h_nhi = a.tile_halo[4 * tile + 3]; }
@@ -281,10 +282,9 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         return r < 0 ? tile_n0 + slot : (r < h_nlo ? h_lo + r : (r < h_nlo + h_nhi ? h_hi + (r - h_nlo) : tile_n0));
     };
 
-    const int e = tile_e0 + wave * 32 + c;
-    const int ec = e < tile_e1 ? e : (tile_e1 > tile_e0 ? tile_e1 - 1 : 0);
-    int sl = a.edge_slot[ec];
-    if (tile_e1 == tile_e0) sl = 0;
+    // slot pair of this lane's edge: stored per TILE ([tile][128], zero past the tile's edges), so the load depends on nothing but
+    // the workgroup's index (not on rowptr: one memory round trip less on the tile's critical path)
+    const int sl = a.edge_slot[(size_t)tile * TILE_EDGES + wave * 32 + c];
     const float* prow = pl + (sl & 255) * PQLD + 4 * hh;
     const float* qrow = ql + ((sl >> 8) & 255) * PQLD + 4 * hh;
 
@@ -332,24 +332,44 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         wload(0);
         wload(1);
         {
+            // Rows of the tile's OWN nodes (slot < nt_: node = tile_n0 + slot) are requested first: their addresses depend on nothing
+            // but the workgroup's index, so these loads leave together with the weight fragments above while the scalar loads of
+            // the halo description are still in flight; the halo slots' rows follow (exec-masked complements: a lane loads once).
             f32x4 hv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int idx = tid + 256 * i;
-                const int node = node_of(idx >> 5);
-                hv[i] = *reinterpret_cast<const f32x4*>(a.h + (size_t)node * H + 4 * (idx & 31));
+                const int idx = tid + 256 * i, slot = idx >> 5;
+                hv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (slot < nt_) hv[i] = *reinterpret_cast<const f32x4*>(a.h + (size_t)(tile_n0 + slot) * H + 4 * (idx & 31));
             }
-            const int tn = node_of(tid >> 3);
+            const int tslot = tid >> 3;
             const int g = tid & 7;
             float tx[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            if (packed_feat) {
+            if (packed_feat && tslot < nt_) {
 #pragma unroll
                 for (int jc = 0; jc < 2; ++jc)
                     if (jc < ntail) {
-                        const f32x4 fv = *reinterpret_cast<const f32x4*>(a.feat + (size_t)tn * (32 * ntail) + 32 * jc + 4 * g);
+                        const f32x4 fv = *reinterpret_cast<const f32x4*>(a.feat + (size_t)(tile_n0 + tslot) * (32 * ntail) + 32 * jc + 4 * g);
 #pragma unroll
                         for (int m = 0; m < 4; ++m) tx[jc][m] = fv[m];
                     }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i, slot = idx >> 5;
+                if (slot >= nt_) hv[i] = *reinterpret_cast<const f32x4*>(a.h + (size_t)node_of(slot) * H + 4 * (idx & 31));
+            }
+            const int tn = node_of(tslot);
+            if (packed_feat) {
+                if (tslot >= nt_) {
+#pragma unroll
+                    for (int jc = 0; jc < 2; ++jc)
+                        if (jc < ntail) {
+                            const f32x4 fv = *reinterpret_cast<const f32x4*>(a.feat + (size_t)tn * (32 * ntail) + 32 * jc + 4 * g);
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) tx[jc][m] = fv[m];
+                        }
+                }
             } else {
 #pragma unroll
                 for (int jc = 0; jc < 2; ++jc)
@@ -562,6 +582,24 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
     const float cexp = -1.44269504088896340736f * inv2;
     const float post = inv2;
 #endif
+    // Swish of the accumulators IN PLACE, all four waves at once (with the activation inside the rounds, two waves computed it
+    // while the other two waited at the round's barrier: the vector work of this phase ran twice in series)
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+#if MSMP_PRECISE_ACT
+            y[T][r] = swishf(y[T][r] * inv2);
+            y[T][r + 1] = swishf(y[T][r + 1] * inv2);
+#else
+            const f32x2 yy = {y[T][r], y[T][r + 1]};
+            const f32x2 t = yy * f32x2{cexp, cexp};
+            const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+            const f32x2 z = yy * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            y[T][r] = z[0];
+            y[T][r + 1] = z[1];
+#endif
+        }
     f32x4 sum[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) sum[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -575,24 +613,8 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
 #pragma unroll
             for (int T = 0; T < 4; ++T)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v;
-#if MSMP_PRECISE_ACT
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) v[m] = swishf(y[T][4 * q + m] * inv2);
-#else
-#pragma unroll
-                    for (int m = 0; m < 4; m += 2) {
-                        const f32x2 yy = {y[T][4 * q + m], y[T][4 * q + m + 1]};
-                        const f32x2 t = yy * f32x2{cexp, cexp};
-                        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
-                        const f32x2 z = yy * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-                        v[m] = z[0];
-                        v[m + 1] = z[1];
-                    }
-#endif
-                    *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = v;
-                }
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = f32x4{y[T][4 * q], y[T][4 * q + 1], y[T][4 * q + 2], y[T][4 * q + 3]};
         }
         TPROF(7);
         __syncthreads();

@@ -92,7 +92,7 @@ class GraphStructure(object):
             tile_node = torch.empty(n_tiles * _lib.MSMP_TILE_NCAP, dtype=torch.int32, device=dev)
             tile_count = torch.empty(n_tiles, dtype=torch.int32, device=dev)
             tile_halo = torch.empty(n_tiles * 4, dtype=torch.int32, device=dev)
-            edge_slot = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
+            edge_slot = torch.empty(n_tiles * _lib.MSMP_TILE_EDGES, dtype=torch.int32, device=dev)
             stats = torch.empty(2, dtype=torch.int32, device=dev)
             check(L.msmp_build_tiles(ptr(self.rowptr), ptr(self.col), self.n_nodes, self.n_edges, tn, ptr(tile_node), ptr(tile_count),
                                      ptr(tile_halo), ptr(edge_slot), ptr(stats), current_stream()), 'msmp_build_tiles')

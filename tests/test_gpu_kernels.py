@@ -588,7 +588,7 @@ def test_node_tiles_are_a_valid_cover(mp, exp, bsz, nx, neighbors):
     tn, n_tiles = desc.tile_nodes, desc.n_tiles
     rowptr, col = gs.rowptr.cpu().numpy(), gs.col.cpu().numpy()[:gs.n_edges]
     tile_node = tile_node.cpu().numpy().reshape(n_tiles, _lib.MSMP_TILE_NCAP)
-    tile_count, edge_slot = tile_count.cpu().numpy(), edge_slot.cpu().numpy()[:gs.n_edges]
+    tile_count, edge_slot = tile_count.cpu().numpy(), edge_slot.cpu().numpy().reshape(n_tiles, _lib.MSMP_TILE_EDGES)
     assert n_tiles == -(-gs.n_nodes // tn)
     for ti in range(n_tiles):
         n0, n1 = ti * tn, min((ti + 1) * tn, gs.n_nodes)
@@ -601,8 +601,9 @@ def test_node_tiles_are_a_valid_cover(mp, exp, bsz, nx, neighbors):
         assert set(extra.tolist()) == set(col[e0:e1][(col[e0:e1] < n0) | (col[e0:e1] >= n1)].tolist())
         assert np.all((nodes >= 0) & (nodes < gs.n_nodes))
         tgt_of_edge = np.searchsorted(rowptr, np.arange(e0, e1), side='right') - 1
-        assert np.array_equal(n0 + (edge_slot[e0:e1] & 255), tgt_of_edge)
-        assert np.array_equal(nodes[(edge_slot[e0:e1] >> 8) & 255], col[e0:e1])
+        assert np.array_equal(n0 + (edge_slot[ti, :e1 - e0] & 255), tgt_of_edge)
+        assert np.array_equal(nodes[(edge_slot[ti, :e1 - e0] >> 8) & 255], col[e0:e1])
+        assert not edge_slot[ti, e1 - e0:].any()
         lo, nlo, hi, nhi = tile_halo[ti]
         if nlo >= 0:        # ranged tile: the list is [targets | lo run | hi run], which the kernel reproduces arithmetically
             want = np.concatenate([np.arange(n0, n1), np.arange(lo, lo + nlo), np.arange(hi, hi + nhi)])
