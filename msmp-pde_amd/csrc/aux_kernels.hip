@@ -106,8 +106,25 @@ __global__ __launch_bounds__(256) void pack_layer_scale_kernel(PackArgs a) {
     const int k1 = 2 * H + a.tw + 1 + a.nv, k3 = 2 * H + a.nv;
     const float* w = blockIdx.x == 0 ? a.w1 : blockIdx.x == 1 ? a.w2 : blockIdx.x == 2 ? a.w3 : a.w4;
     const int n = H * (blockIdx.x == 0 ? k1 : blockIdx.x == 2 ? k3 : H);
+    // n is a multiple of 128; four independent 16-byte loads in flight per thread (one 4-byte load per step left this kernel at
+    // 22 us: 12 of them per training iteration)
+    f32x4 mv[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+    const int n4 = n / 4;
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = i + 256 * u;
+            const f32x4 v = w4[k < n4 ? k : i];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) mv[u][x] = fmaxf(mv[u][x], fabsf(v[x]));
+        }
+    }
     float m = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) m = fmaxf(m, mv[u][x]);
     red[threadIdx.x] = m;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {

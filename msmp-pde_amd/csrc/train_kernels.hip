@@ -245,47 +245,60 @@ __device__ __forceinline__ Bf3 split_bf16x3(const float (&x)[8]) {
 // loop is bound by load latency otherwise (measured: a 9-tile body with one block in flight ran 2.6x SLOWER than the fp32-MFMA
 // kernel it replaced, ten dependent memory round trips per block).
 constexpr int GW_NT = 5;
-struct GwBlock {
-    float a[8];
-    float b[GW_NT][8];
+constexpr int GW_FRAG_U4 = GW_NT * 3 * 64;           // 16-byte fragments of one 16-row block of B: [tile][plane][lane] = 15 KB
+
+// One 16-row block: lane (m, kk) of wave w loads rows rbase .. rbase + 7 of column 32 w + m of A (its own MFMA operand) and of
+// column c0 + 32 w + m of B (tile w); tile 4 of the group is loaded by the wave whose turn it is (block index mod 4).  Every load is
+// a 128-byte row segment across 32 lanes.  B is converted ONCE per workgroup and shared through LDS as bf16x3 fragments: with every
+// wave loading and converting all five tiles itself (first round-2 edition) the B rows crossed the L1 four times and the
+// conversion was 85 % of the vector work.
+struct GwRegs {
+    float a[8], b[8], b4[8];
 };
-// rows rbase .. rbase + 7 of this lane's column of A and of every tile's column of B; `rlim` = number of valid rows from rbase on
-// (>= 8 on the fast path: no row predicate at all)
 template <bool FULL>
-__device__ __forceinline__ void gw_load(const GradWeightJob& j, const float* acol, const float* const (&bcol)[GW_NT], int rbase, int rlim, GwBlock& blk) {
+__device__ __forceinline__ void gw_load(const GradWeightJob& j, const float* acol, const float* bcol, const float* bcol4, bool mine4, int rbase,
+                                        int rlim, GwRegs& r) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int r = FULL ? rbase + i : rbase + min(i, max(rlim - 1, 0));
-        const float v = acol[(size_t)r * j.lda];
-        blk.a[i] = FULL || i < rlim ? v : 0.f;
+        const size_t row = FULL ? rbase + i : rbase + min(i, max(rlim - 1, 0));
+        const bool in = FULL || i < rlim;
+        const float va = acol[row * j.lda], vb = bcol[row * j.ldb];
+        r.a[i] = in ? va : 0.f;
+        r.b[i] = in ? vb : 0.f;
     }
-#pragma unroll
-    for (int t = 0; t < GW_NT; ++t)
+    if (mine4) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int r = FULL ? rbase + i : rbase + min(i, max(rlim - 1, 0));
-            const float v = bcol[t][(size_t)r * j.ldb];
-            blk.b[t][i] = FULL || i < rlim ? v : 0.f;
+            const size_t row = FULL ? rbase + i : rbase + min(i, max(rlim - 1, 0));
+            const float v = bcol4[row * j.ldb];
+            r.b4[i] = FULL || i < rlim ? v : 0.f;
         }
+    }
 }
-__device__ __forceinline__ void gw_compute(const GwBlock& blk, const float (&keep)[GW_NT], const float (&ones)[GW_NT], f32x16 (&acc)[GW_NT]) {
-    const Bf3 a3 = split_bf16x3(blk.a);
+__device__ __forceinline__ void gw_publish(const float (&b)[8], float keep, float ones, u32x4* frag_tile, int lane) {
+    float bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = fmaf(b[i], keep, ones);          // column past k2: 0; the bias column k2: 1
+    const Bf3 b3 = split_bf16x3(bv);
+    frag_tile[lane] = __builtin_bit_cast(u32x4, b3.hi);
+    frag_tile[64 + lane] = __builtin_bit_cast(u32x4, b3.mid);
+    frag_tile[128 + lane] = __builtin_bit_cast(u32x4, b3.lo);
+}
+__device__ __forceinline__ void gw_mma(const Bf3& a3, const u32x4* frags, int lane, f32x16 (&acc)[GW_NT]) {
 #pragma unroll
     for (int t = 0; t < GW_NT; ++t) {
-        float bv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) bv[i] = fmaf(blk.b[t][i], keep[t], ones[t]);      // column past k2: 0; the bias column k2: 1
-        const Bf3 b3 = split_bf16x3(bv);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.lo, b3.hi, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.hi, b3.lo, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.mid, b3.mid, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.mid, b3.hi, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.hi, b3.mid, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.hi, b3.hi, acc[t], 0, 0, 0);
+        const u32x4* f = frags + (size_t)t * 3 * 64 + lane;
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, f[0]), bm = __builtin_bit_cast(bf16x8, f[64]), bl = __builtin_bit_cast(bf16x8, f[128]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.lo, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.hi, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.mid, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.mid, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.hi, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.hi, bh, acc[t], 0, 0, 0);
     }
 }
 
-__device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int split, int wave, int lane) {
+__device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int split, int wave, int lane, u32x4* frags /* LDS [2][GW_FRAG_U4] */) {
     const int m = lane & 31, kk = lane >> 5;
     f32x16 acc[GW_NT];
 #pragma unroll
@@ -293,45 +306,38 @@ __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int spl
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int r0 = split * j.rows_per_split, r1 = min(r0 + j.rows_per_split, j.rows);
-    // lane (m, kk) holds rows rb + 8 kk .. + 7 of column 32 wave + m of A (the MFMA's A operand: 8 consecutive k per lane) and of
-    // column c0 + 32 t + m of B for each of the group's tiles; every load is a 128-byte row segment across the 32 lanes.
     const float* acol = j.a + 32 * wave + m;
-    const float* bcol[GW_NT];
-    float keep[GW_NT], ones[GW_NT];
-#pragma unroll
-    for (int t = 0; t < GW_NT; ++t) {
+    auto colptr = [&](int t, float& keep, float& ones) {
         const int c = j.c0 + 32 * t + m;
-        bcol[t] = j.b + (c < j.k2 ? c : 0);
-        keep[t] = c < j.k2 ? 1.0f : 0.f;
-        ones[t] = c == j.k2 ? 1.0f : 0.f;
-    }
-    const int n_full = (r1 - r0) / 16;                   // whole 16-row blocks; a ragged rest takes the predicated path once
-    GwBlock b0, b1;
-    int rb = r0;
-    // the scheduling barriers pin "all loads of the NEXT block, then the whole matrix work of the current one": left alone the
-    // compiler sinks the loads next to their uses (fewer live registers) and the loop waits for memory ten times per block
-    if (n_full > 0) gw_load<true>(j, acol, bcol, rb + 8 * kk, 8, b0);
+        keep = c < j.k2 ? 1.0f : 0.f;
+        ones = c == j.k2 ? 1.0f : 0.f;
+        return j.b + (c < j.k2 ? c : 0);
+    };
+    float keep, ones, keep4, ones4;
+    const float* bcol = colptr(wave, keep, ones);
+    const float* bcol4 = colptr(4, keep4, ones4);
+    const int n_blocks = (r1 - r0 + 15) / 16;            // the last one may be ragged: it takes the predicated loads
+    const int n_full = (r1 - r0) / 16;
+    GwRegs cur, nxt;
+    auto load_block = [&](int blk, GwRegs& dst) {
+        const int rb = r0 + 16 * blk + 8 * kk;
+        if (blk < n_full) gw_load<true>(j, acol, bcol, bcol4, (blk & 3) == wave, rb, 8, dst);
+        else gw_load<false>(j, acol, bcol, bcol4, (blk & 3) == wave, min(rb, r1 - 1), r1 - rb, dst);
+    };
+    if (n_blocks > 0) load_block(0, cur);
     __builtin_amdgcn_sched_barrier(0);
-    int k = 0;
-    for (; k + 2 <= n_full; k += 2) {
-        gw_load<true>(j, acol, bcol, rb + 16 + 8 * kk, 8, b1);
+    for (int blk = 0; blk < n_blocks; ++blk) {
+        if (blk + 1 < n_blocks) load_block(blk + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);               // all loads of the next block are requested before this block's work
+        u32x4* fb = frags + (size_t)(blk & 1) * GW_FRAG_U4;
+        gw_publish(cur.b, keep, ones, fb + (size_t)wave * 3 * 64, lane);
+        if ((blk & 3) == wave) gw_publish(cur.b4, keep4, ones4, fb + (size_t)4 * 3 * 64, lane);
+        const Bf3 a3 = split_bf16x3(cur.a);
+        __syncthreads();                                 // fragments of this block visible; the other buffer is free for the next block
+        gw_mma(a3, fb, lane, acc);
         __builtin_amdgcn_sched_barrier(0);
-        gw_compute(b0, keep, ones, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 2 < n_full) gw_load<true>(j, acol, bcol, rb + 32 + 8 * kk, 8, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        gw_compute(b1, keep, ones, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        rb += 32;
-    }
-    if (k < n_full) {                                    // one full block left (loaded into b0)
-        gw_compute(b0, keep, ones, acc);
-        rb += 16;
-    }
-    if (rb < r1) {
-        const int rlim = r1 - (rb + 8 * kk);              // valid rows of this lane's half block (may be <= 0)
-        gw_load<false>(j, acol, bcol, min(rb + 8 * kk, r1 - 1), rlim, b0);
-        gw_compute(b0, keep, ones, acc);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { cur.a[i] = nxt.a[i]; cur.b[i] = nxt.b[i]; cur.b4[i] = nxt.b4[i]; }
     }
     float* p = j.partial + (size_t)split * H * j.ldp + j.c0;
 #pragma unroll
@@ -341,13 +347,14 @@ __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int spl
             if (j.c0 + 32 * t < j.ldp) p[(size_t)(32 * wave + acc_row(r, kk)) * j.ldp + 32 * t + m] = acc[t][r];
 }
 
-__global__ __launch_bounds__(256, 2) void grad_weight_kernel(GradWeightArgs a) {
+__global__ __launch_bounds__(256, 3) void grad_weight_kernel(GradWeightArgs a) {
     int ji = 0;
 #pragma unroll
     for (int i = 1; i < GW_MAX_UNITS; ++i)
         if (i < a.n_units && (int)blockIdx.x >= a.unit[i].first_block) ji = i;
     const GradWeightJob& j = a.unit[ji];
-    grad_weight_body(j, blockIdx.x - j.first_block, threadIdx.x >> 6, threadIdx.x & 63);
+    __shared__ u32x4 frags[2 * GW_FRAG_U4];              // 30 KB
+    grad_weight_body(j, blockIdx.x - j.first_block, threadIdx.x >> 6, threadIdx.x & 63, frags);
 }
 
 // out[row][col] = sum over splits, in split order; grid.y = job

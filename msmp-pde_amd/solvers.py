@@ -37,29 +37,23 @@ _TOEPLITZ = {}
 
 def _conv1d_as_matmul(x, weight, bias, stride):
     """Conv1d(x [N, Cin, Lin]; weight [Cout, Cin, k], stride) as ONE dense GEMM [N, Cin Lin] x T [Cin Lin, Cout Lout], T the
-    convolution's Toeplitz matrix, itself a fixed 0/1 selection matrix times the flattened `weight` (differentiable both ways as GEMVs).
+    convolution's Toeplitz matrix, itself the weight times a fixed 0/1 shift tensor (differentiable both ways as small GEMMs).
     The decoder's convolutions have 1-2 input and 8 output channels: as unfold + einsum they are [N L, 16] x [16, 8] products for
     which the library picked a 32x16-tile kernel (3.7 ms of a 48-ms training iteration at batch 512, plus the unfold backward);
     as Toeplitz products they are [N,128] x [128,304] and [N,304] x [304,25]: well-shaped GEMMs forward and backward."""
     cout, cin, k = weight.shape
     n, _, lin = x.shape
     lout = (lin - k) // stride + 1
-    key = (cout, cin, k, lin, stride, x.device, weight.dtype)
+    key = (k, lin, stride, x.device, weight.dtype)
     if key not in _TOEPLITZ:
-        i = torch.arange(lin, device=x.device)[:, None] - stride * torch.arange(lout, device=x.device)[None, :]      # tap index, [Lin, Lout]
-        valid = (i >= 0) & (i < k)
-        tap = i.clamp(0, k - 1)
-        ci = torch.arange(cin, device=x.device)[:, None, None, None]
-        co = torch.arange(cout, device=x.device)[None, None, :, None]
-        idx = ((co * cin + ci) * k + tap[None, :, None, :]).reshape(-1)                                                 # [Cin Lin Cout Lout]
-        mask = valid[None, :, None, :].expand(cin, lin, cout, lout).reshape(-1)
-        # selection matrix S [Cin Lin Cout Lout, Cout Cin k] with T = S w: a GEMV forward and backward (a gather's backward would be a
-        # sorted index_put: milliseconds at these sizes)
-        sel = torch.zeros(idx.numel(), cout * cin * k, dtype=weight.dtype, device=x.device)
-        rows = torch.nonzero(mask).reshape(-1)
-        sel[rows, idx[rows]] = 1
-        _TOEPLITZ[key] = sel
-    t = (_TOEPLITZ[key] @ weight.reshape(-1)).view(cin * lin, cout * lout)
+        # E[tap, i, l] = 1 where input position i feeds output position l through that tap (i = stride l + tap): T = w . E is a
+        # [Cout Cin, k] x [k, Lin Lout] product forward and backward (a gather's backward would be a sorted index_put, a dense
+        # selection matrix over all of T's entries a 20-MB GEMV per call)
+        i = torch.arange(lin, device=x.device)[None, :, None]
+        l = torch.arange(lout, device=x.device)[None, None, :]
+        tap = torch.arange(k, device=x.device)[:, None, None]
+        _TOEPLITZ[key] = (i == stride * l + tap).to(weight.dtype).reshape(k, lin * lout)
+    t = (weight.reshape(cout * cin, k) @ _TOEPLITZ[key]).view(cout, cin, lin, lout).permute(1, 2, 0, 3).reshape(cin * lin, cout * lout)
     out = x.reshape(n, cin * lin) @ t
     return out.view(n, cout, lout) + bias[None, :, None]
 
