@@ -327,7 +327,9 @@ def run_rank(args):
                                f'{"radius graph n=" if exp in ("E2", "MSWG3") else "knn graph k="}{args.neighbors}',
                    'graphs_total': head['graphs_total'], 'graphs_per_gpu': head['graphs_this_rank'], 'nodes_per_gpu': n_nodes, 'edges_per_gpu': n_edges,
                    'parallelism': f'dp{world} (graph-sharded, no collective in the rollout)',
-                   'graph_steps_per_s': head['graph_steps_per_s'], 'output_finite': head['output_finite'],
+                   'graph_steps_per_s': head['graph_steps_per_s'],
+                   'edge_steps_per_s': head['graph_steps_per_s'] * n_edges / max(head['graphs_this_rank'], 1),
+                   'output_finite': head['output_finite'],
                    'preheat': f'{head["preheat_steps"]} untimed steps (>= {args.preheat_s:g} s) after the {args.warmup} warm-up steps'},
         # `achieved` counts the USEFUL fp32 GEMM FLOPs the dominant kernel computes (message_net_2 per edge + the per-node projections
         # once per node; the factorised form removed 69 % of row L1's dense FLOPs).  They execute on the fp16 matrix pipe (2-way fp16 split of both operands, 3 MFMAs per K=16 step, fp32-class
@@ -390,6 +392,33 @@ def run_rank(args):
                               'frac': sc_bytes / (sc_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 'algorithmic_bytes_per_launch': sc_bytes,
                               'avg_launch_ms': sc_ms}
         del msg, agg
+        # SURVEY 8d "GPU timing": (ii) the forward alone and the graph construction (once per rollout, outside the timed region), both
+        # timed here after the timed region on the workload's own batch
+        wl_main = head_wl
+        with torch.no_grad():
+            for i in range(13):
+                if i == 3:
+                    torch.cuda.synchronize()
+                    t_f = time.perf_counter()
+                wl_main.model(wl_main.graph)
+            torch.cuda.synchronize()
+            fwd_ms = (time.perf_counter() - t_f) / 10 * 1e3
+            steps0 = [50] * wl_main.bsz
+            t_g = []
+            for i in range(3):
+                torch.cuda.synchronize()
+                t0g = time.perf_counter()
+                data_g, labels_g = wl_main.case.creator.create_data(wl_main.case.u_super, steps0)
+                g_new = wl_main.case.creator.create_graph(data_g, labels_g, wl_main.case.x, wl_main.case.variables, steps0)
+                gs_new = structure_of(g_new)
+                gs_new.tiles()
+                torch.cuda.synchronize()
+                t_g.append((time.perf_counter() - t0g) * 1e3)
+        out['breakdown'] = {'forward_only_ms': fwd_ms, 'state_update_ms': head['ms_per_step'] - fwd_ms,
+                            'graph_construction_ms': min(t_g),
+                            'note': 'forward_only = model(graph) alone; state_update = create_data labels + create_next_graph (the rest of a step); '
+                                    'graph_construction = create_data + create_graph (radius / knn graph on the device) + CSR + node tiles, once per rollout, '
+                                    'not part of a step'}
     if world == 1 and not args.no_extras:
         # BASELINE.json configs[0]: E2 MP-PDE on 32 graphs (the reference's own CPU-runnable case), HIP path and CPU port
         a0 = parse(['--model', 'MP-PDE', '--experiment', 'E2', '--graphs', '32'])
