@@ -293,6 +293,13 @@ int msmp_decoder2d_f32(const float* hd, const float* u, int64_t n_nodes, int tw,
                        const float* b1, const float* w2, const float* b2, float dt, float* out,
                        msmp_stream_t stream);
 
+/* `double_mlp` of the *2D solver classes, experiments/models_gnn2D.py:66-70 (nn.Linear(128, 256) + Swish; the Unflatten is a view):
+ * out [rows, n_out] = Swish(x [rows, k] w^T + bias), w [n_out, k] in nn.Linear's layout; n_out a multiple of 128, k a multiple of 4 up to 288.
+ * fp32-exact products on the bf16 matrix pipe.  workspace: msmp_linear_swish_workspace_bytes(k, n_out) bytes (0 = unsupported sizes). */
+size_t msmp_linear_swish_workspace_bytes(int k, int n_out);
+int msmp_linear_swish_f32(const float* x, int64_t rows, int k, const float* w, const float* bias, int n_out, float* out,
+                          void* workspace, size_t workspace_bytes, msmp_stream_t stream);
+
 /* msmp_lem_encoder_f32 with the step inputs assembled in the kernel from the node arrays (no [N, T, ninp] tensor in HBM):
  *   two_d = 0: x_t = [pos_x, u_t, variables]                                experiments/models_gnn.py:1357-1360, ninp = 2 + nv
  *   two_d = 1: x_t = [pos_x, u_t, u_{tw+t}, dt_cum_t + pos_t, variables[1:]]  experiments/models_gnn2D.py:429-433, ninp = 3 + nv

@@ -635,6 +635,7 @@ static void carve(float*& p, long n, long e, int ld_e, int ld_n, HeadBuf& b) {
 //   EPI 1: acc + bias -> out0                                (recompute of an output layer)
 //   EPI 2: acc * Swish'(aux) -> out0                         (data gradient through a hidden layer)
 //   EPI 3: acc -> out0                                       (data gradient w.r.t. the layer input; 256 columns = two launches)
+//   EPI 4: Swish(acc + bias) -> out0                         (msmp_linear_swish_f32: the *2D classes' double_mlp)
 // ----------------------------------------------------------------------------------------------------------------------
 constexpr int RG_CHUNK_U4 = 2 * 4 * 3 * 64;            // 16-byte fragments per 32-k chunk: [s][T][plane][lane]
 constexpr int RG_CHUNK_FLOATS = RG_CHUNK_U4 * 4;       // 24 KB
@@ -761,13 +762,17 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RgArgs a) {
     }
     // ---- epilogue: lane c holds channels 4 c .. 4 c + 3 (tiles T = 0..3) of rows row0 + acc_row(r, hh) -----------------------
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (EPI <= 1) bias4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * c);
+    if (EPI <= 1 || EPI == 4) bias4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * c);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const long row = row0 + acc_row(r, hh);
         if (row >= a.rows) continue;
         f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-        if (EPI <= 1) v += bias4;
+        if (EPI <= 1 || EPI == 4) v += bias4;
+        if (EPI == 4) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) v[m] = swishf(v[m]);
+        }
         if (EPI == 2) {
             const f32x4 pre = *reinterpret_cast<const f32x4*>(a.aux + (size_t)row * H + 4 * c);
 #pragma unroll
@@ -791,6 +796,7 @@ static int rows_gemm(int epi, const float* x, int ldx, long rows, int K, const u
         case 0: hipLaunchKernelGGL(rows_gemm_kernel<0>, grid, dim3(256), 0, st, a); break;
         case 1: hipLaunchKernelGGL(rows_gemm_kernel<1>, grid, dim3(256), 0, st, a); break;
         case 2: hipLaunchKernelGGL(rows_gemm_kernel<2>, grid, dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(rows_gemm_kernel<4>, grid, dim3(256), 0, st, a); break;
         default: hipLaunchKernelGGL(rows_gemm_kernel<3>, grid, dim3(256), 0, st, a); break;
     }
     return check_launch("rows_gemm_kernel");
@@ -926,6 +932,35 @@ static int64_t bwd_gw_floats(long n, long e, int kmsg, int kupd, int heads) {
 }
 
 }  // namespace msmp
+
+// Swish(x W^T + b) for a row-major x [rows, k] and a Linear weight w [n_out, k] (n_out a multiple of 128, k <= 288 a multiple of 4):
+// the `double_mlp` of the *2D solver classes (experiments/models_gnn2D.py:66-70: Linear(128, 256) + Swish + Unflatten) on the row-GEMM
+// kernel above (fp32-exact bf16x3 products), one launch per 128 output columns after one weight-split launch.
+extern "C" size_t msmp_linear_swish_workspace_bytes(int k, int n_out) {
+    if (k < 4 || k > 288 || k % 4 || n_out < 128 || n_out % 128 || n_out > 128 * RG_MAX_PACK) return 0;
+    return (size_t)(n_out / 128) * ((k + 31) / 32) * RG_CHUNK_U4 * sizeof(u32x4) + 256;
+}
+extern "C" int msmp_linear_swish_f32(const float* x, int64_t rows, int k, const float* w, const float* bias, int n_out, float* out,
+                                     void* workspace, size_t workspace_bytes, msmp_stream_t stream) {
+    MSMP_REQUIRE(x && w && bias && out && workspace, MSMP_ERR_ARG, "msmp_linear_swish_f32: null pointer");
+    const size_t need = msmp_linear_swish_workspace_bytes(k, n_out);
+    MSMP_REQUIRE(need, MSMP_ERR_UNSUPPORTED, "msmp_linear_swish_f32: k = %d (a multiple of 4 up to 288), n_out = %d (a multiple of 128 up to %d)", k, n_out, 128 * RG_MAX_PACK);
+    MSMP_REQUIRE(rows > 0 && rows < (1L << 31), MSMP_ERR_ARG, "msmp_linear_swish_f32: bad rows");
+    MSMP_REQUIRE(workspace_bytes >= need, MSMP_ERR_WORKSPACE, "msmp_linear_swish_f32: workspace %zu < %zu", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    u32x4* fp = reinterpret_cast<u32x4*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const int groups = n_out / 128, chunks = (k + 31) / 32;
+    RgPackArgs pa;
+    pa.n_jobs = 0;
+    int blocks = 0;
+    for (int g = 0; g < groups; ++g) add_pack(pa, blocks, w, k, k, 128 * g, 0, fp + (size_t)g * chunks * RG_CHUNK_U4);
+    for (int i = pa.n_jobs; i < RG_MAX_PACK; ++i) pa.job[i] = pa.job[0];
+    hipLaunchKernelGGL(rg_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pa);
+    RC(check_launch("rg_pack_kernel"));
+    for (int g = 0; g < groups; ++g)
+        RC(rows_gemm(4, x, k, (long)rows, k, fp + (size_t)g * chunks * RG_CHUNK_U4, bias + 128 * g, nullptr, out + 128 * g, n_out, nullptr, st));
+    return MSMP_OK;
+}
 
 extern "C" size_t msmp_mp_layer_bwd_workspace_bytes(int64_t n_nodes, int64_t n_edges, int tw, int nv, int gated) {
     if (n_nodes <= 0 || n_edges < 0 || tw < 1 || nv < 1 || nv > MSMP_MAX_VARS) return 0;

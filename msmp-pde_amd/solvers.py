@@ -11,8 +11,8 @@ Reference classes:
   MP_PDE_SolverLEMLin / MP_PDE_Solver2DLEMLin   models_gnn.py:619-756 / models_gnn2D.py:920-1057   ("LEM" / "LEM2D" ablations)
 Inference (no autograd) runs on HIP kernels end to end: the encoder (msmp_lem_encoder_nodes_f32 with lemoutput_mlp fused, or
 msmp_mlp2_swish_f32 for embedding_mlp), the L x [message -> mean -> update -> InstanceNorm (-> gate blend)] loop
-(msmp_mp_layer_f32) and the decoder CNN with the Euler update (msmp_decoder_f32 / msmp_decoder2d_f32); only `double_mlp` of
-the 2-D classes and a few feature-preparation ops are PyTorch-ROCm.  Under autograd the layers and the LEM encoder use their
+(msmp_mp_layer_f32), `double_mlp` of the 2-D classes (msmp_linear_swish_f32) and the decoder CNN with the Euler update
+(msmp_decoder_f32 / msmp_decoder2d_f32).  Under autograd the layers and the LEM encoder use their
 HIP forward / backward pairs (autograd.py, lem.py) and the small encoder / decoder modules PyTorch-ROCm ops.  `pde.L`,
 `pde.tmax`, `pde.dt` are read at call time (they are mutated after construction, experiments/train.py:355-358).  Compute
 dtype is float32; the result is returned in the dtype of `data.x`.
@@ -347,7 +347,7 @@ class _SolverBase(nn.Module):
             diff = _decoder_autograd(self.double_mlp(h), self.output_mlp[0], self.output_mlp[2])
             out = (u.view(-1, 2, tw) + dt.view(1, 1, tw) * diff).flatten(1, 2)
         elif self.TWO_D:                # fused: conv(2->8) -> Swish -> conv(8->2) -> u + cumsum(dt) * diff
-            hd = self.double_mlp(h).contiguous()
+            hd = self._double_mlp_hip(h)
             out = torch.empty_like(u)
             c1, c2 = self.output_mlp[0], self.output_mlp[2]
             w = [p.detach().to(torch.float32).contiguous() for p in (c1.weight, c1.bias, c2.weight, c2.bias)]   # kept alive
@@ -365,6 +365,25 @@ class _SolverBase(nn.Module):
                                          ptr(w[3]), float(self.pde.dt), ptr(out), current_stream()), 'msmp_decoder_f32')
         return out.to(u_in.dtype)
 
+
+    def _double_mlp_hip(self, h):
+        """double_mlp (models_gnn2D.py:66-70: Linear(128, 256) + Swish + Unflatten) as one HIP row GEMM with the bias and the Swish in its
+        epilogue (msmp_linear_swish_f32); returns [N, 2, 128]."""
+        lin = self.double_mlp[0]
+        w, b = lin.weight.detach().to(torch.float32).contiguous(), lin.bias.detach().to(torch.float32).contiguous()
+        h = h.contiguous()
+        n_out, k = w.shape
+        need = lib().msmp_linear_swish_workspace_bytes(k, n_out)
+        if not need:
+            raise RuntimeError(f'double_mlp of {k} -> {n_out} features is outside msmp_linear_swish_f32')
+        ws = getattr(self, '_dmlp_ws', None)
+        if ws is None or ws.numel() < need or ws.device != h.device:
+            ws = self._dmlp_ws = torch.empty(need, dtype=torch.uint8, device=h.device)
+        out = torch.empty(h.shape[0], n_out, dtype=torch.float32, device=h.device)
+        check(lib().msmp_linear_swish_f32(ptr(h), h.shape[0], k, ptr(w), ptr(b), n_out, ptr(out), ptr(ws), ws.numel(), current_stream()),
+              'msmp_linear_swish_f32')
+        self._dmlp_keep = (w, b)          # alive until the stream has consumed them
+        return out.view(h.shape[0], 2, n_out // 2)
 
     def capture(self, data):
         """hipGraph of `forward` for a fixed graph batch (inference): returns `step(data) -> prediction` that copies the

@@ -679,3 +679,28 @@ def test_tiled_message_kernel_vs_gather_kernels_and_oracle(mp, exp, tw, nv, bsz,
     err_ga = np.abs(ref.double().cpu().numpy() - agg).max() / den
     print(f'{exp} tw={tw}: relative max error vs float64 oracle: tile kernel folded {err:.2e}, staged {err_st:.2e}, gather kernels {err_ga:.2e}')
     assert err < 1e-6 and err_st < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,k,n_out', [(1000, 128, 256), (1, 128, 256), (333, 36, 128), (4097, 288, 384)])
+def test_linear_swish_vs_float64(mp, rows, k, n_out):
+    """msmp_linear_swish_f32 (the *2D classes' double_mlp: Swish(x W^T + b)) against float64, incl. ragged last row tiles, K that is
+    no multiple of 32 and more than two 128-column groups; unsupported sizes are refused."""
+    from msmp_pde_amd._lib import check, ptr, current_stream
+    L = mp.lib()
+    g = torch.Generator().manual_seed(rows + k)
+    x = torch.randn(rows, k, generator=g).cuda()
+    w = (torch.randn(n_out, k, generator=g) / k ** 0.5).cuda()
+    b = (torch.randn(n_out, generator=g) * 0.1).cuda()
+    need = L.msmp_linear_swish_workspace_bytes(k, n_out)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    out = torch.full((rows, n_out), float('nan'), device='cuda')
+    check(L.msmp_linear_swish_f32(ptr(x), rows, k, ptr(w), ptr(b), n_out, ptr(out), ptr(ws), need, current_stream()), 'linear_swish')
+    z = x.double() @ w.double().t() + b.double()
+    ref = z * torch.sigmoid(z)
+    err = (out.double() - ref).abs().max().item()
+    print(f'linear_swish {rows}x{k}->{n_out}: max error {err:.2e}')
+    assert err < 2e-6 * max(ref.abs().max().item(), 1.0)
+    assert L.msmp_linear_swish_workspace_bytes(130, 256) == 0 and L.msmp_linear_swish_workspace_bytes(128, 200) == 0
+    assert L.msmp_linear_swish_f32(ptr(x), rows, k, ptr(w), ptr(b), n_out, ptr(out), ptr(ws), 16, current_stream()) != 0
