@@ -1018,6 +1018,22 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
     }
 }
 
+// fp32 chunks [128 out][32 k] (row-major, as `rec`) -> bf16x3 A fragments, acc order: thread = (chunk, s, T, lane)
+__global__ __launch_bounds__(256) void pack_lem_b3_kernel(const float* __restrict__ chunks, int n_chunks, float* __restrict__ out) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= n_chunks * 512) return;
+    const int lane = id & 63, T = (id >> 6) & 3, s = (id >> 8) & 1, ch = id >> 9;
+    const int m = lane & 31, hh = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = chunks[(size_t)ch * CHUNK_FLOATS + (32 * T + m) * KC + split_k_acc(s, hh, j)];
+    const Bf3 f = split_bf16x3(v);
+    u32x4* dst = reinterpret_cast<u32x4*>(out) + (size_t)ch * LEM_B3_CHUNK_U4 + (size_t)((s * 4 + T) * 3) * 64 + lane;
+    dst[0] = __builtin_bit_cast(u32x4, f.hi);
+    dst[64] = __builtin_bit_cast(u32x4, f.mid);
+    dst[128] = __builtin_bit_cast(u32x4, f.lo);
+}
+
 }  // namespace msmp
 
 using namespace msmp;
@@ -1038,6 +1054,8 @@ extern "C" int msmp_pack_lem_f32(const float* weights, const float* weights_lin_
     hipLaunchKernelGGL(pack_lem_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(pack_lem_scale_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(pack_lem_split_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(pack_lem_b3_kernel, dim3(16 * 512 / 256), dim3(256), 0, (hipStream_t)stream, packed_out + lem_layout().rec, 16,
+                       packed_out + lem_layout().rec_b3);
     return check_launch("pack_lem_kernel");
 }
 

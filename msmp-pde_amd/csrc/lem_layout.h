@@ -7,6 +7,9 @@
 namespace msmp {
 
 constexpr int LEM_MAX_INP = 8;
+// one [128 out][32 k] chunk as bf16 hi / mid / lo MFMA A fragments, acc order: [s 2][T 4][plane 3][lane 64][8 bf16] = 24 KB
+constexpr int LEM_B3_CHUNK_U4 = 2 * 4 * 3 * 64;
+constexpr int LEM_B3_CHUNK_FLOATS = LEM_B3_CHUNK_U4 * 4;
 // input columns as fp16 "slot" fragments (weight-stationary kernel): [4 groups g2,g3,g1,lin][4 T][2 m][64 lanes][8 halfs]
 constexpr int LEM_WXH_FLOATS = 4 * 4 * 2 * 64 * 8 / 2;
 
@@ -25,9 +28,10 @@ __host__ __device__ inline int lem_slot_part(int slot, int P) { return slot / P;
 //   fp16-split copies for the split kernel (mfma_tiles.h): scales [8] (2^s of W, Wz, Wa, Wb, then 2^-s) |
 //   rec_s (16 split chunks, acc order, same consumption order) | mlp_s (8 split chunks) |
 //   bias_s [512], wxf_s [4096], mlpb_s [256]: the fp32 bias / input-column fragments pre-multiplied by 2^s of their matrix |
-//   wx_h: the scaled input columns as fp16 slot fragments (see lem_slot_feature)
+//   wx_h: the scaled input columns as fp16 slot fragments (see lem_slot_feature) |
+//   rec_b3: the 16 recurrent chunks as bf16x3 fragments, acc order (training forward: fp32-exact products on the bf16 pipe)
 struct LemLayout {
-    int64_t rec, mlp, bias, wx, mlpb, scales, rec_s, mlp_s, bias_s, wx_s, mlpb_s, wx_h, total;
+    int64_t rec, mlp, bias, wx, mlpb, scales, rec_s, mlp_s, bias_s, wx_s, mlpb_s, wx_h, rec_b3, total;
 };
 
 __host__ __device__ inline LemLayout lem_layout() {
@@ -45,6 +49,7 @@ __host__ __device__ inline LemLayout lem_layout() {
     L.wx_s = o; o += 4 * H * LEM_MAX_INP;
     L.mlpb_s = o; o += 2 * H;
     L.wx_h = o; o += LEM_WXH_FLOATS;
+    L.rec_b3 = o; o += 16 * LEM_B3_CHUNK_FLOATS;
     L.total = o;
     return L;
 }

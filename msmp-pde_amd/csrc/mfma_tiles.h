@@ -231,6 +231,37 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[4][NB]) {
 }
 
 // Host/device: value of element (s, T, plane, lane, j) of a split chunk built from W[row][k0 + k] (row stride ld).
+// fp32 products on the bf16 matrix pipe: x = hi + mid + lo EXACTLY with three truncated 8-bit pieces (bf16 has fp32's exponent
+// range, so gradients of any magnitude survive -- the fp16 split of the inference kernels would need a per-tensor scale), and
+//   a b = hi hi + (hi mid + mid hi) + (mid mid + hi lo + lo hi) + O(2^-24 a b):  six MFMAs per K = 16 step, fp32 accumulation.
+// 6 x 32 cycles per 16 rows against 8 x 64 for v_mfma_f32_32x32x2_f32: the matrix time drops 2.7x and the kernel becomes what it
+// should be, bound by reading A and B once (round 2; the exact-fp32 edition ran at 30 % of the fp32 MFMA peak, 9.4 ms per
+// batch-512 iteration).
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+struct Bf3 {
+    bf16x8 hi, mid, lo;
+};
+__device__ __forceinline__ Bf3 split_bf16x3(const float (&x)[8]) {
+    u32x4 h, m, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned hb[2], mb[2], lb[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float v = x[2 * i + k];
+            hb[k] = __float_as_uint(v) & 0xffff0000u;
+            const float r1 = v - __uint_as_float(hb[k]);              // exact
+            mb[k] = __float_as_uint(r1) & 0xffff0000u;
+            lb[k] = __float_as_uint(r1 - __uint_as_float(mb[k]));     // exact; its top 16 bits are taken by the permute below
+        }
+        h[i] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);      // {x1.b3, x1.b2, x0.b3, x0.b2}: two bf16 per register
+        m[i] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
+        l[i] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
+    }
+    return Bf3{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, m), __builtin_bit_cast(bf16x8, l)};
+}
+
 __host__ __device__ inline int split_k_natural(int s, int h, int j) { return 16 * s + 8 * h + j; }
 __host__ __device__ inline int split_k_acc(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 
