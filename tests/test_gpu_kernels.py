@@ -704,3 +704,53 @@ def test_linear_swish_vs_float64(mp, rows, k, n_out):
     assert err < 2e-6 * max(ref.abs().max().item(), 1.0)
     assert L.msmp_linear_swish_workspace_bytes(130, 256) == 0 and L.msmp_linear_swish_workspace_bytes(128, 200) == 0
     assert L.msmp_linear_swish_f32(ptr(x), rows, k, ptr(w), ptr(b), n_out, ptr(out), ptr(ws), 16, current_stream()) != 0
+
+
+@pytest.mark.gpu
+def test_integration_md_bindings_run(mp):
+    """The ctypes stubs printed in INTEGRATION.md (what a reference maintainer would paste into GNN_LayerLin.forward and its autograd
+    Function) are executed as printed -- only the library path is substituted -- and compared with this package's own layer: forward
+    bit-identical on the gather path both take without tiles, backward against autograd through the package's layer."""
+    import os, re
+    from msmp_pde_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blocks = re.findall(r'```python\n(.*?)```', open(os.path.join(root, 'INTEGRATION.md')).read(), re.S)
+    code = [b for b in blocks if 'hip_layer_forward' in b or 'hip_layer_backward' in b]
+    assert len(code) == 2
+    ns = {}
+    for b in code:
+        exec(b.replace("'msmp-pde_amd/libmsmp_pde.so'", repr(_lib.LIB_PATH)), ns)
+    torch.manual_seed(4)
+    tw, nv, sizes = 25, 2, [70, 100, 31]
+    n = sum(sizes)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).cuda()
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    src, dst = [], []
+    for g, s in enumerate(sizes):        # +-3 neighbours inside each graph
+        for i in range(s):
+            for d in (-3, -2, -1, 1, 2, 3):
+                if 0 <= i + d < s:
+                    src.append(off[g] + i + d); dst.append(off[g] + i)
+    ei = torch.tensor(np.stack([src, dst])).cuda()
+    layer = mp.GNN_LayerLin(H, H, H, tw, nv).cuda()
+    x, u, pos, var = torch.randn(n, H).cuda(), torch.randn(n, tw).cuda(), torch.rand(n, 1).cuda(), torch.rand(n, nv).cuda()
+    out = ns['hip_layer_forward'](layer, x, u, pos.reshape(-1).contiguous(), var, ei, batch, tw, nv, lin=True)
+    xr = x.clone().requires_grad_(True)
+    ref = layer(xr, u, pos, var, ei, batch)
+    assert (out - ref.detach()).abs().max().item() < 2e-6 * ref.detach().abs().max().item()
+    gout = torch.randn_like(ref)
+    ref.backward(gout)
+    from msmp_pde_amd.graph import GraphStructure
+    gs = GraphStructure(ei, batch, n)
+    gp = torch.tensor(off, dtype=torch.int32).cuda()
+    ps = [p.detach().float().contiguous() for p in (layer.message_net_1[0].weight, layer.message_net_1[0].bias, layer.message_net_2[0].weight,
+                                                     layer.message_net_2[0].bias, layer.update_net_1[0].weight, layer.update_net_1[0].bias,
+                                                     layer.update_net_2[0].weight, layer.update_net_2[0].bias)]
+    dx, grads = ns['hip_layer_backward'](gout, x, u, pos.reshape(-1).contiguous(), var, gs.rowptr, gs.col[:gs.n_edges].contiguous(),
+                                         gs.tgt[:gs.n_edges].contiguous(), gp, ps, tw, nv, lin=True)
+    assert (dx - xr.grad).abs().max().item() < 1e-4 * xr.grad.abs().max().item()
+    own = [layer.message_net_1[0].weight.grad, layer.message_net_1[0].bias.grad, layer.message_net_2[0].weight.grad, layer.message_net_2[0].bias.grad,
+           layer.update_net_1[0].weight.grad, layer.update_net_1[0].bias.grad, layer.update_net_2[0].weight.grad, layer.update_net_2[0].bias.grad]
+    scale = max(g.abs().max().item() for g in own)
+    for a_, b_ in zip(grads, own):
+        assert (a_ - b_).abs().max().item() < 1e-4 * scale
