@@ -58,7 +58,8 @@ const char* msmp_last_error(void);
  *   "split"   1 (default): the GEMMs of the node / edge / LEM kernels run on the fp16 matrix pipe with a 2-way
  *             fp16 split of both operands (fp32-class accuracy); 0: the fp32-MFMA kernels.
  *   "edge_nb" 0 auto, 1 / 2 force the 128- / 256-edge tile of the factorised message kernel.
- *   "tile"    2 (default): with node tiles, project P / Q inside the message kernel; 1: msmp_node_project_f32 + tile kernel on the
+ *   "tile"    2 (default): with node tiles that are at least 60 % full (>= 76 edges per tile on average), project P / Q inside the message
+ *             kernel, else the gather kernels; 3: the same regardless of the fill; 1: msmp_node_project_f32 + tile kernel on the
  *             staged P / Q rows; 0: ignore the tiles (gather kernels).
  *   "bwd_gemm" 1 (default): msmp_mp_layer_bwd_f32 runs its row GEMMs on its own bf16x3 MFMA kernel (fused bias / Swish / dSwish epilogues) from
  *             32 768 edges on and on rocblas_sgemm below; 0: always the library; 2: always its own kernel.

@@ -500,7 +500,13 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
     float* qbuf = (float*)(ws + 4 * nod);
     int rc;
     // message + mean (rows L1 + L2): one fused launch when every target's in-edges fit a workgroup tile
-    const int tile_mode = (tiles && n_edges > 0 && msmp_tune_get("split")) ? msmp_tune_get("tile") : 0;
+    // Tiles pay when they are full: a tile is a 128-edge block of matrix work whatever it holds.  Structures whose tiles stay half
+    // empty (32 node slots are used up before 128 edges: knn graphs of in-degree 3 on a scattered grid, RPU: 66 edges per tile)
+    // run the untiled kernels (measured at 2048 graphs, ms per rollout step, tiled / untiled: RPU 7.00 / 6.77, WE3 at 84 edges
+    // per tile 5.72 / 5.92, E2 at 123: 6.6 / 7.1).  "tile" 3 forces the tiles.
+    int tile_mode = (tiles && n_edges > 0 && msmp_tune_get("split")) ? msmp_tune_get("tile") : 0;
+    if (tile_mode == 2 && n_edges < (int64_t)76 * tiles->n_tiles) tile_mode = 0;
+    if (tile_mode == 3) tile_mode = 2;
     auto aggregate = [&](const float* packed, float* agg) -> int {
         if (fused && !dense && tile_mode == 2)       // node tiles staged in LDS, P / Q computed in the workgroup
             return msmp_edge_aggregate_tiled_f32(h, u, pos, vars, feat, nullptr, nullptr, rowptr, tiles, n_nodes, n_edges, tw, nv, packed, agg, stream);
