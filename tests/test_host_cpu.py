@@ -225,3 +225,22 @@ def test_bench_launcher_starts_one_rank_per_gpu():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launcher-selftest'], env=env2,
                         capture_output=True, text=True, timeout=300)
     assert r2.returncode != 0 and 'WORLD_SIZE=1' in r2.stderr
+
+
+def test_decoder_convolution_as_toeplitz_gemm_matches_conv1d():
+    """solvers._conv1d_as_matmul (the AUTOGRAD decoder: Conv1d as one dense GEMM against the convolution's Toeplitz matrix, itself the
+    weight times a fixed shift tensor) against torch.nn.functional.conv1d, forward and all three gradients, for every decoder geometry
+    of the reference (models_gnn.py:210-224, models_gnn2D.py:79-88) in float64 on the CPU."""
+    import torch
+    from msmp_pde_amd.solvers import _conv1d_as_matmul
+    torch.manual_seed(0)
+    for cin, cout, k, s, lin in [(1, 8, 16, 3, 128), (8, 1, 14, 1, 38), (2, 8, 16, 3, 128), (8, 2, 14, 1, 38), (1, 8, 15, 4, 128), (8, 1, 10, 1, 29),
+                                 (1, 8, 12, 2, 128), (8, 1, 10, 1, 59), (2, 8, 12, 2, 128), (8, 2, 10, 1, 59)]:
+        x = torch.randn(5, cin, lin, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(cout, cin, k, dtype=torch.float64, requires_grad=True)
+        b = torch.randn(cout, dtype=torch.float64, requires_grad=True)
+        y, yr = _conv1d_as_matmul(x, w, b, s), torch.nn.functional.conv1d(x, w, b, stride=s)
+        assert y.shape == yr.shape and (y - yr).abs().max().item() < 1e-12
+        g = torch.randn_like(y)
+        for ga, gr in zip(torch.autograd.grad(y, (x, w, b), g), torch.autograd.grad(yr, (x, w, b), g)):
+            assert (ga - gr).abs().max().item() < 1e-11
