@@ -32,7 +32,8 @@ def _linear(i, o):
 
 
 class _Workspace(object):
-    """Grow-only scratch buffer per device, shared by all layers (the C-ABI never allocates).  `private(device)` is a context
+    """Grow-only scratch buffer per (device, stream), shared by all layers (the C-ABI never allocates; forwards issued on different
+    streams of one device must not share scratch memory).  `private(device)` is a context
     in which the layers of the calling thread use buffers of their own instead (hipGraph capture: the captured launches must
     point at memory nobody replaces; solvers._GraphedForward keeps those buffers alive as long as the graph)."""
     _bufs = {}
@@ -64,10 +65,11 @@ class _Workspace(object):
                 assert not torch.cuda.is_current_stream_capturing() or p.buf is None, 'workspace grew during capture'
                 p.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             return p.buf
-        buf = cls._bufs.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        buf = cls._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            cls._bufs[device] = buf
+            cls._bufs[key] = buf
         return buf
 
 

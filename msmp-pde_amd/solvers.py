@@ -376,9 +376,8 @@ class _SolverBase(nn.Module):
         need = lib().msmp_linear_swish_workspace_bytes(k, n_out)
         if not need:
             raise RuntimeError(f'double_mlp of {k} -> {n_out} features is outside msmp_linear_swish_f32')
-        ws = getattr(self, '_dmlp_ws', None)
-        if ws is None or ws.numel() < need or ws.device != h.device:
-            ws = self._dmlp_ws = torch.empty(need, dtype=torch.uint8, device=h.device)
+        from .layers import _Workspace
+        ws = _Workspace.get(need, h.device)         # per (device, stream); the layers are done with it by now
         out = torch.empty(h.shape[0], n_out, dtype=torch.float32, device=h.device)
         check(lib().msmp_linear_swish_f32(ptr(h), h.shape[0], k, ptr(w), ptr(b), n_out, ptr(out), ptr(ws), ws.numel(), current_stream()),
               'msmp_linear_swish_f32')

@@ -445,3 +445,33 @@ def test_input_range_guard_and_exact_fp32_fallback(mp):
     err = np.abs(out.double().cpu().numpy() - ref).max()
     print(f'offset input (|u| ~ 1000) on the exact-fp32 kernels: max|hip - oracle| = {err:.3e} on outputs of magnitude {np.abs(ref).max():.4g}')
     assert np.isfinite(out.cpu().numpy()).all() and err < 2e-3 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+def test_forwards_on_two_streams_do_not_share_scratch(mp):
+    """Two batches evaluated concurrently on two streams of one device (what an overlapped rollout of sub-batches does) give the bits of
+    the one-after-the-other evaluation: the layers' scratch workspace is per (device, stream)."""
+    from msmp_pde_amd.synthetic import make_case
+    torch.manual_seed(6)
+    kind = 'MP_PDE_Solver2DLEMLinGated'
+    cases = [make_case('MSWG3', b, seed=20 + b, device='cuda', dtype=torch.float32) for b in (40, 64)]
+    model = getattr(mp, kind)(cases[0].pde, time_window=TW, eq_variables=cases[0].eqv, hidden_layer=2).cuda().eval()
+    graphs = []
+    for c in cases:
+        steps = [50] * c.u_super.shape[0]
+        data, labels = c.creator.create_data(c.u_super, steps)
+        graphs.append(c.creator.create_graph(data, labels, c.x, c.variables, steps))
+    with torch.no_grad():
+        ref = [model(g).clone() for g in graphs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for rep in range(3):
+            outs = []
+            for g, s in zip(graphs, streams):
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    for _ in range(3):
+                        o = model(g)
+                    outs.append(o)
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(outs, ref)), rep
