@@ -193,7 +193,7 @@ extern "C" int msmp_gate_blend_bwd_f32(const float* grad_out, const float* h, co
 // ----------------------------------------------------------------------------------------------
 namespace msmp {
 
-constexpr int GW_MAX_JOBS = 8;
+constexpr int GW_MAX_JOBS = 10;
 constexpr int GW_MAX_UNITS = 2 * GW_MAX_JOBS;       // a job of more than 160 columns is two column groups
 struct GradWeightJob {
     const float* a;      // [rows, lda], columns 0..127 used
@@ -525,14 +525,15 @@ __global__ __launch_bounds__(256) void add_cols_kernel(float* __restrict__ dh, c
 
 // dh[i] += sum over the in-edges e of i of d[e][0..127]   (CSR order: deterministic), thread = (node, channel group)
 __global__ __launch_bounds__(256) void scatter_target_kernel(float* __restrict__ dh, const float* __restrict__ d, int ld,
-                                                             const int* __restrict__ rowptr, long n_nodes) {
+                                                             const int* __restrict__ rowptr, long n_nodes, int overwrite = 0) {
     const long total = n_nodes * (H / 4);
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
         const long n = p >> 5;
         const int cg = (int)(p & 31);
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) s += *reinterpret_cast<const f32x4*>(d + (size_t)e * ld + 4 * cg);
-        reinterpret_cast<f32x4*>(dh)[p] += s;
+        if (overwrite) reinterpret_cast<f32x4*>(dh)[p] = s;
+        else reinterpret_cast<f32x4*>(dh)[p] += s;
     }
 }
 
@@ -551,21 +552,97 @@ __global__ __launch_bounds__(256) void scatter_source_kernel(float* __restrict__
 // source), thread = (node, channel group): run-to-run bitwise reproducible gradients
 __global__ __launch_bounds__(256) void scatter_source_sorted_kernel(float* __restrict__ dh, const float* __restrict__ d, int ld,
                                                                     const int* __restrict__ src_rowptr, const int* __restrict__ src_perm,
-                                                                    long n_nodes) {
+                                                                    long n_nodes, int col_off = H, int overwrite = 0) {
     const long total = n_nodes * (H / 4);
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
         const long n = p >> 5;
         const int cg = (int)(p & 31);
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int k = src_rowptr[n]; k < src_rowptr[n + 1]; ++k)
-            s += *reinterpret_cast<const f32x4*>(d + (size_t)src_perm[k] * ld + H + 4 * cg);
-        reinterpret_cast<f32x4*>(dh)[p] += s;
+            s += *reinterpret_cast<const f32x4*>(d + (size_t)src_perm[k] * ld + col_off + 4 * cg);
+        if (overwrite) reinterpret_cast<f32x4*>(dh)[p] = s;
+        else reinterpret_cast<f32x4*>(dh)[p] += s;
     }
 }
 
 static unsigned grid_for(long work_items) {
     const long b = (work_items + 255) / 256;
     return (unsigned)(b < 1 ? 1 : b > 32768 ? 32768 : b);
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// message_net_1 WITHOUT edge-sized GEMMs in the backward (round 2).  Its input row is [h_i, h_j, u_i - u_j, p_i - p_j, v_i]:
+//   forward    a1_e = P[tgt_e] + Q[src_e],   P = W1[:, h_i | u | p | v] F_i + b1,   Q = W1[:, h_j | -u | -p] F_j,   F = [h | u | p | v] per NODE
+//   backward   with S_t[i] = sum over in-edges of d a1, S_s[j] = sum over out-edges of d a1 (both in a fixed order):
+//              dh += S_t W1[:, h_i] + S_s W1[:, h_j];   dW1[:, h_i | u,p | v] = S_t^T F,   dW1[:, h_j] and the negative u, p part = S_s^T F;   db1 = sum S_t
+// i.e. the [E,284] input, its two 284- / 256-wide GEMMs and the largest weight-gradient reduction become node-sized (E = 5.9 N).
+// ----------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void node_feat_kernel(const float* __restrict__ h, const float* __restrict__ u, const float* __restrict__ pos,
+                                                        const float* __restrict__ vars, long n_nodes, int tw, int nv, int ldf, float* __restrict__ out) {
+    const int g4 = ldf / 4;
+    const long total = n_nodes * g4;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const long n = p / g4;
+        const int g = (int)(p - n * g4);
+        f32x4 v;
+        if (g < 32) v = *reinterpret_cast<const f32x4*>(h + (size_t)n * H + 4 * g);
+        else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int k = 4 * (g - 32) + m;
+                v[m] = k < tw ? u[(size_t)n * tw + k] : (k == tw ? pos[n] : (k <= tw + nv ? vars[(size_t)n * nv + (k - tw - 1)] : 0.f));
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)n * ldf + 4 * g) = v;
+    }
+}
+// WP[o][:] = [W1[o][0:128] | W1[o][256:256+tw+1+nv] | 0],  WQ[o][:] = [W1[o][128:256] | -W1[o][256:256+tw+1] | 0]
+__global__ __launch_bounds__(256) void pq_weights_kernel(const float* __restrict__ w1, int kmsg, int tw, int nv, int ldf, float* __restrict__ wp,
+                                                         float* __restrict__ wq) {
+    const int total = H * ldf;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+        const int o = p / ldf, k = p - o * ldf;
+        float vp = 0.f, vq = 0.f;
+        if (k < H) { vp = w1[(size_t)o * kmsg + k]; vq = w1[(size_t)o * kmsg + H + k]; }
+        else if (k - H < tw + 1 + nv) {
+            vp = w1[(size_t)o * kmsg + H + k];           // column 256 + (k - 128)
+            if (k - H < tw + 1) vq = -vp;
+        }
+        wp[p] = vp;
+        wq[p] = vq;
+    }
+}
+// a1[e] = P[tgt[e]] + Q[src[e]],  m1[e] = Swish(a1[e])   (thread = edge x 16-byte channel group)
+__global__ __launch_bounds__(256) void edge_gather_add_kernel(const float* __restrict__ P, const float* __restrict__ Q, const int* __restrict__ tgt,
+                                                              const int* __restrict__ src, long n_edges, float* __restrict__ a1, float* __restrict__ m1) {
+    const long total = n_edges * 32;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const long e = p >> 5;
+        const int cg = (int)(p & 31);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(P + (size_t)tgt[e] * H + 4 * cg) + *reinterpret_cast<const f32x4*>(Q + (size_t)src[e] * H + 4 * cg);
+        f32x4 s;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) s[m] = swishf(v[m]);
+        reinterpret_cast<f32x4*>(a1)[p] = v;
+        reinterpret_cast<f32x4*>(m1)[p] = s;
+    }
+}
+// dW1 [128, kmsg] from  t1 = S_t^T F [128, kf]  and  t2 = S_s^T F [128, kq]   (kf = 128 + tw + 1 + nv, kq = 128 + tw + 1)
+__global__ __launch_bounds__(256) void combine_w1_kernel(const float* __restrict__ t1, const float* __restrict__ t2, int kf, int kq, int kmsg, int tw,
+                                                         float* __restrict__ dw1) {
+    const int total = H * kmsg;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+        const int o = p / kmsg, k = p - o * kmsg;
+        float v;
+        if (k < H) v = t1[(size_t)o * kf + k];
+        else if (k < 2 * H) v = t2[(size_t)o * kq + (k - H)];
+        else {
+            const int j = k - 2 * H;                     // tail column
+            v = t1[(size_t)o * kf + H + j];
+            if (j < tw + 1) v -= t2[(size_t)o * kq + H + j];
+        }
+        dw1[p] = v;
+    }
 }
 
 struct BwdCtx {
@@ -579,10 +656,15 @@ struct BwdCtx {
 struct HeadBuf {      // per head: recompute intermediates and gradient scratch
     float *cat_e, *a1, *m1, *a2, *x2, *x1, *dcat_e;             // edge-sized: [E, ld_e], 5 x [E,128], [E,256]
     float *agg, *cat_n, *a3, *u1, *upd, *dupd, *x3, *dcat_n;    // node-sized: [N,128], [N, ld_n], 5 x [N,128], [N,256]
+    // factorised message_net_1: node features F [N, ldf] (shared by the heads), P, Q, S_t, S_s [N,128], WP, WQ [128, ldf],
+    // weight-gradient pieces t1 [128, kf], t2 [128, kq], an unused bias row [128]
+    float *feat, *P, *Q, *st, *ss, *wp, *wq, *t1, *t2, *tb;
 };
+static int fact_ldf(int tw, int nv) { return H + 32 * ((tw + 1 + nv + 31) / 32); }
 
 static size_t head_floats(long n, long e, int ld_e, int ld_n) {
-    return (size_t)e * (ld_e + 5 * H + 2 * H) + (size_t)n * (H + ld_n + 5 * H + 2 * H);
+    const int ldf = H + 64;      // upper bound of fact_ldf (tw + 1 + nv <= 64)
+    return (size_t)e * (ld_e + 5 * H + 2 * H) + (size_t)n * (H + ld_n + 5 * H + 2 * H) + (size_t)n * (ldf + 4 * H) + 4 * (size_t)H * ldf + H + 10 * 64;
 }
 
 static void carve(float*& p, long n, long e, int ld_e, int ld_n, HeadBuf& b) {
@@ -591,6 +673,9 @@ static void carve(float*& p, long n, long e, int ld_e, int ld_n, HeadBuf& b) {
     b.x2 = take((size_t)e * H); b.x1 = take((size_t)e * H); b.dcat_e = take((size_t)e * 2 * H);
     b.agg = take((size_t)n * H); b.cat_n = take((size_t)n * ld_n); b.a3 = take((size_t)n * H); b.u1 = take((size_t)n * H);
     b.upd = take((size_t)n * H); b.dupd = take((size_t)n * H); b.x3 = take((size_t)n * H); b.dcat_n = take((size_t)n * 2 * H);
+    const int ldf = H + 64;
+    b.feat = take((size_t)n * ldf); b.P = take((size_t)n * H); b.Q = take((size_t)n * H); b.st = take((size_t)n * H); b.ss = take((size_t)n * H);
+    b.wp = take((size_t)H * ldf); b.wq = take((size_t)H * ldf); b.t1 = take((size_t)H * ldf); b.t2 = take((size_t)H * ldf); b.tb = take(H);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -606,6 +691,7 @@ static void carve(float*& p, long n, long e, int ld_e, int ld_n, HeadBuf& b) {
 //   EPI 2: acc * Swish'(aux) -> out0                         (data gradient through a hidden layer)
 //   EPI 3: acc -> out0                                       (data gradient w.r.t. the layer input; 256 columns = two launches)
 //   EPI 4: Swish(acc + bias) -> out0                         (msmp_linear_swish_f32: the *2D classes' double_mlp)
+//   EPI 5: out0 += acc                                       (node-level data gradient of the factorised message_net_1)
 // ----------------------------------------------------------------------------------------------------------------------
 constexpr int RG_CHUNK_U4 = 2 * 4 * 3 * 64;            // 16-byte fragments per 32-k chunk: [s][T][plane][lane]
 constexpr int RG_CHUNK_FLOATS = RG_CHUNK_U4 * 4;       // 24 KB
@@ -618,7 +704,7 @@ struct RgPackJob {
     // transposed = 1: W_eff[o][k] = w[k * ldw + col0 + o]     (data-gradient form: the reduction runs over w's rows)
     int first_block;
 };
-constexpr int RG_MAX_PACK = 20;
+constexpr int RG_MAX_PACK = 24;
 struct RgPackArgs {
     RgPackJob job[RG_MAX_PACK];
     int n_jobs;
@@ -748,6 +834,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RgArgs a) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) v[m] *= dswish(pre[m]);
         }
+        if (EPI == 5) v += *reinterpret_cast<const f32x4*>(a.out0 + (size_t)row * a.ld0 + 4 * c);
         *reinterpret_cast<f32x4*>(a.out0 + (size_t)row * a.ld0 + 4 * c) = v;
         if (EPI == 0) {
             f32x4 sw;
@@ -767,6 +854,7 @@ static int rows_gemm(int epi, const float* x, int ldx, long rows, int K, const u
         case 1: hipLaunchKernelGGL(rows_gemm_kernel<1>, grid, dim3(256), 0, st, a); break;
         case 2: hipLaunchKernelGGL(rows_gemm_kernel<2>, grid, dim3(256), 0, st, a); break;
         case 4: hipLaunchKernelGGL(rows_gemm_kernel<4>, grid, dim3(256), 0, st, a); break;
+        case 5: hipLaunchKernelGGL(rows_gemm_kernel<5>, grid, dim3(256), 0, st, a); break;
         default: hipLaunchKernelGGL(rows_gemm_kernel<3>, grid, dim3(256), 0, st, a); break;
     }
     return check_launch("rows_gemm_kernel");
@@ -776,22 +864,29 @@ static int rows_gemm(int epi, const float* x, int ldx, long rows, int K, const u
 struct HeadFrags {
     u32x4 *w1, *w2, *w3, *w4;            // forward forms (K = kmsg, 128, kupd, 128)
     u32x4 *w4t, *w3t[2], *w2t, *w1t[2];  // data-gradient forms (reduction over the 128 output channels; 128-column groups of the input)
+    u32x4 *wp, *wq;                      // factorised message_net_1: the per-node projections (K = fact_ldf)
 };
 static size_t head_frag_u4(int kmsg, int kupd) {
-    return (size_t)RG_CHUNK_U4 * ((kmsg + 31) / 32 + 4 + (kupd + 31) / 32 + 4 + 6 * 4);
+    return (size_t)RG_CHUNK_U4 * ((kmsg + 31) / 32 + 4 + (kupd + 31) / 32 + 4 + 6 * 4 + 2 * 6);
 }
 static void carve_frags(u32x4*& p, int kmsg, int kupd, HeadFrags& f) {
     auto take = [&](int chunks) { u32x4* r = p; p += (size_t)chunks * RG_CHUNK_U4; return r; };
     f.w1 = take((kmsg + 31) / 32); f.w2 = take(4); f.w3 = take((kupd + 31) / 32); f.w4 = take(4);
     f.w4t = take(4); f.w3t[0] = take(4); f.w3t[1] = take(4); f.w2t = take(4); f.w1t[0] = take(4); f.w1t[1] = take(4);
+    f.wp = take(6); f.wq = take(6);
 }
 static void add_pack(RgPackArgs& a, int& blocks, const float* w, int ldw, int K, int col0, int transposed, u32x4* out) {
     RgPackJob& j = a.job[a.n_jobs++];
     j.w = w; j.out = out; j.ldw = ldw; j.K = K; j.n_chunks = (K + 31) / 32; j.col0 = col0; j.transposed = transposed; j.first_block = blocks;
     blocks += (j.n_chunks * 512 + 255) / 256;
 }
-static int pack_head_frags(const float* const* p, int kmsg, int kupd, const HeadFrags& f, RgPackArgs& a, int& blocks) {
-    add_pack(a, blocks, p[0], kmsg, kmsg, 0, 0, f.w1);
+static int pack_head_frags(const float* const* p, int kmsg, int kupd, const HeadFrags& f, RgPackArgs& a, int& blocks, const float* wp, const float* wq,
+                           int ldf) {
+    if (wp) {        // factorised message_net_1: the projection weights replace the [128, kmsg] forward form
+        add_pack(a, blocks, wp, ldf, ldf, 0, 0, f.wp);
+        add_pack(a, blocks, wq, ldf, ldf, 0, 0, f.wq);
+    } else
+        add_pack(a, blocks, p[0], kmsg, kmsg, 0, 0, f.w1);
     add_pack(a, blocks, p[2], H, H, 0, 0, f.w2);
     add_pack(a, blocks, p[4], kupd, kupd, 0, 0, f.w3);
     add_pack(a, blocks, p[6], H, H, 0, 0, f.w4);
@@ -811,11 +906,21 @@ static int pack_head_frags(const float* const* p, int kmsg, int kupd, const Head
 static int head_recompute(const BwdCtx& c, Blas& bl, const HeadFrags* fr, const float* const* p, HeadBuf& b, bool build_cat_e) {
     const long n = c.n, e = c.e;
     if (e) {
-        if (build_cat_e) RC(msmp_edge_concat_f32(c.h, c.u, c.pos, c.vars, c.tgt, c.col, e, c.tw, c.nv, c.ld_e, b.cat_e, c.st));
-        if (fr) {
+        const bool fact = fr && c.src_rowptr;       // message_net_1 through the per-node projections (no [E, kmsg] input, no edge-sized GEMM)
+        if (fact) {
+            const int ldf = fact_ldf(c.tw, c.nv);
+            if (build_cat_e)
+                hipLaunchKernelGGL(node_feat_kernel, dim3(grid_for(n * (ldf / 4))), dim3(256), 0, c.st, c.h, c.u, c.pos, c.vars, n, c.tw, c.nv, ldf, b.feat);
+            RC(rows_gemm(1, b.feat, ldf, n, ldf, fr->wp, p[1], nullptr, b.P, H, nullptr, c.st));
+            RC(rows_gemm(3, b.feat, ldf, n, ldf, fr->wq, nullptr, nullptr, b.Q, H, nullptr, c.st));
+            hipLaunchKernelGGL(edge_gather_add_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.P, b.Q, c.tgt, c.col, e, b.a1, b.m1);
+            RC(rows_gemm(0, b.m1, H, e, H, fr->w2, p[3], nullptr, b.a2, H, b.x2, c.st));
+        } else if (fr) {
+            if (build_cat_e) RC(msmp_edge_concat_f32(c.h, c.u, c.pos, c.vars, c.tgt, c.col, e, c.tw, c.nv, c.ld_e, b.cat_e, c.st));
             RC(rows_gemm(0, b.cat_e, c.ld_e, e, c.kmsg, fr->w1, p[1], nullptr, b.a1, H, b.m1, c.st));
             RC(rows_gemm(0, b.m1, H, e, H, fr->w2, p[3], nullptr, b.a2, H, b.x2, c.st));
         } else {
+            if (build_cat_e) RC(msmp_edge_concat_f32(c.h, c.u, c.pos, c.vars, c.tgt, c.col, e, c.tw, c.nv, c.ld_e, b.cat_e, c.st));
             BLAS_OK(gemm_nt(bl, (int)e, H, c.kmsg, b.cat_e, c.ld_e, p[0], c.kmsg, b.a1, H), "message_net_1");
             hipLaunchKernelGGL(bias_silu_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.a1, p[1], b.m1, e * 32);
             BLAS_OK(gemm_nt(bl, (int)e, H, H, b.m1, H, p[2], H, b.a2, H), "message_net_2");
@@ -863,7 +968,19 @@ static int head_backward(const BwdCtx& c, Blas& bl, const HeadFrags* fr, const f
     hipLaunchKernelGGL(add_cols_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, dh, b.dcat_n, 2 * H, n);
     if (e) {
         hipLaunchKernelGGL(mean_bwd_dswish_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.dcat_n + H, 2 * H, c.rowptr, c.tgt, b.a2, e, b.x2);   // d a2
-        if (fr) {
+        const bool fact = fr && c.src_rowptr;
+        if (fact) {
+            const int ldf = fact_ldf(c.tw, c.nv), kf = H + c.tw + 1 + c.nv, kq = H + c.tw + 1;
+            RC(rows_gemm(2, b.x2, H, e, H, fr->w2t, nullptr, b.a1, b.x1, H, nullptr, c.st));                                     // d a1
+            // S_t / S_s: d a1 summed over each node's in- / out-edges, fixed order (CSR by target; the by-source regrouping)
+            hipLaunchKernelGGL(scatter_target_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, b.st, b.x1, H, c.rowptr, n, 1);
+            hipLaunchKernelGGL(scatter_source_sorted_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, b.ss, b.x1, H, c.src_rowptr, c.src_perm, n, 0, 1);
+            RC(rows_gemm(5, b.st, H, n, H, fr->w1t[0], nullptr, nullptr, dh, H, nullptr, c.st));                                 // dh += S_t W1[:, h_i]
+            RC(rows_gemm(5, b.ss, H, n, H, fr->w1t[1], nullptr, nullptr, dh, H, nullptr, c.st));                                 // dh += S_s W1[:, h_j]
+            jobs.add(b.st, b.feat, n, ldf, kf, b.t1, grads[1]);          // S_t^T F and db1 = column sums of S_t
+            jobs.add(b.ss, b.feat, n, ldf, kq, b.t2, b.tb);
+            jobs.add(b.x2, b.m1, e, H, H, grads[2], grads[3]);
+        } else if (fr) {
             RC(rows_gemm(2, b.x2, H, e, H, fr->w2t, nullptr, b.a1, b.x1, H, nullptr, c.st));                                     // d a1
             RC(rows_gemm(3, b.x1, H, e, H, fr->w1t[0], nullptr, nullptr, b.dcat_e, 2 * H, nullptr, c.st));                       // [d x_i |
             RC(rows_gemm(3, b.x1, H, e, H, fr->w1t[1], nullptr, nullptr, b.dcat_e + H, 2 * H, nullptr, c.st));                   //  d x_j]
@@ -872,14 +989,16 @@ static int head_backward(const BwdCtx& c, Blas& bl, const HeadFrags* fr, const f
             hipLaunchKernelGGL(dsilu_mul_kernel, dim3(grid_for(e * 32)), dim3(256), 0, c.st, b.x1, b.a1, b.x1, e * 32);         // d a1
             BLAS_OK(gemm_nn(bl, (int)e, 2 * H, H, b.x1, H, p[0], c.kmsg, b.dcat_e, 2 * H), "d message_net_1");                  // [d x_i | d x_j]
         }
-        hipLaunchKernelGGL(scatter_target_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.rowptr, n);
-        if (c.src_rowptr)
-            hipLaunchKernelGGL(scatter_source_sorted_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.src_rowptr,
-                               c.src_perm, n);
-        else
-            hipLaunchKernelGGL(scatter_source_kernel, dim3(grid_for(e * H)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.col, e);
-        jobs.add(b.x1, b.cat_e, e, c.ld_e, c.kmsg, grads[0], grads[1]);
-        jobs.add(b.x2, b.m1, e, H, H, grads[2], grads[3]);
+        if (!fact) {
+            hipLaunchKernelGGL(scatter_target_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.rowptr, n, 0);
+            if (c.src_rowptr)
+                hipLaunchKernelGGL(scatter_source_sorted_kernel, dim3(grid_for(n * 32)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.src_rowptr,
+                                   c.src_perm, n, H, 0);
+            else
+                hipLaunchKernelGGL(scatter_source_kernel, dim3(grid_for(e * H)), dim3(256), 0, c.st, dh, b.dcat_e, 2 * H, c.col, e);
+            jobs.add(b.x1, b.cat_e, e, c.ld_e, c.kmsg, grads[0], grads[1]);
+            jobs.add(b.x2, b.m1, e, H, H, grads[2], grads[3]);
+        }
     } else {          // no edges: the message layers get zero gradients
         hipLaunchKernelGGL(fill_kernel, dim3(grid_for((long)H * c.kmsg)), dim3(256), 0, c.st, grads[0], 0.f, (long)H * c.kmsg);
         hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, c.st, grads[1], 0.f, (long)H);
@@ -898,7 +1017,14 @@ static int64_t bwd_gw_floats(long n, long e, int kmsg, int kupd, int heads) {
         if (e) { rows[j] = e; k2[j++] = kmsg; rows[j] = e; k2[j++] = H; }
         rows[j] = n; k2[j++] = kupd; rows[j] = n; k2[j++] = H;
     }
-    return msmp_grad_weights_workspace_floats(j, rows, k2);
+    const int64_t plain = msmp_grad_weights_workspace_floats(j, rows, k2);
+    j = 0;                                  // factorised message_net_1: two node-sized jobs instead of the [E, kmsg] one
+    for (int hd = 0; hd < heads; ++hd) {
+        if (e) { rows[j] = n; k2[j++] = kmsg - H; rows[j] = n; k2[j++] = kmsg - H; rows[j] = e; k2[j++] = H; }
+        rows[j] = n; k2[j++] = kupd; rows[j] = n; k2[j++] = H;
+    }
+    const int64_t fact = msmp_grad_weights_workspace_floats(j, rows, k2);
+    return plain < 0 || fact < 0 ? -1 : (plain > fact ? plain : fact);
 }
 
 }  // namespace msmp
@@ -995,12 +1121,18 @@ extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, cons
         RgPackArgs pa;
         pa.n_jobs = 0;
         int blocks = 0;
+        const bool fact = src_rowptr != nullptr && c.e > 0;
+        const int ldf = fact_ldf(tw, nv);
+        if (fact) {      // WP / WQ of the per-node projections first: the split launch below reads them
+            hipLaunchKernelGGL(pq_weights_kernel, dim3(grid_for((long)H * ldf)), dim3(256), 0, st, params_main[0], c.kmsg, tw, nv, ldf, bm.wp, bm.wq);
+            if (gated) hipLaunchKernelGGL(pq_weights_kernel, dim3(grid_for((long)H * ldf)), dim3(256), 0, st, params_gate[0], c.kmsg, tw, nv, ldf, bg.wp, bg.wq);
+        }
         carve_frags(fp, c.kmsg, c.kupd, fm);
-        pack_head_frags(params_main, c.kmsg, c.kupd, fm, pa, blocks);
+        pack_head_frags(params_main, c.kmsg, c.kupd, fm, pa, blocks, fact ? bm.wp : nullptr, bm.wq, ldf);
         frm = &fm;
         if (gated) {
             carve_frags(fp, c.kmsg, c.kupd, fg);
-            pack_head_frags(params_gate, c.kmsg, c.kupd, fg, pa, blocks);
+            pack_head_frags(params_gate, c.kmsg, c.kupd, fg, pa, blocks, fact ? bg.wp : nullptr, bg.wq, ldf);
             frg = &fg;
         }
         for (int i = pa.n_jobs; i < RG_MAX_PACK; ++i) pa.job[i] = pa.job[0];
@@ -1011,6 +1143,7 @@ extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, cons
     RC(head_recompute(c, bl, frm, params_main, bm, true));
     if (gated) {
         bg.cat_e = bm.cat_e;                      // both heads read the same per-edge input
+        bg.feat = bm.feat;                        // ... or the same per-node feature rows
         RC(head_recompute(c, bl, frg, params_gate, bg, false));
         RC(msmp_gate_blend_bwd_f32(grad_out, h, bg.upd, bm.upd, graph_ptr, n_graphs, eps, bg.dupd, bm.dupd, dh_out, stream));
         RC(head_backward(c, bl, frm, params_main, bm, dh_out, grads_main, jobs));
@@ -1025,7 +1158,14 @@ extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, cons
         hipLaunchKernelGGL(dsilu_mul_kernel, dim3(grid_for(n4)), dim3(256), 0, st, dh_out, bm.upd, bm.dupd, n4);
         RC(head_backward(c, bl, frm, params_main, bm, dh_out, grads_main, jobs));
     }
-    return launch_grad_weights(jobs.n, jobs.a, jobs.b, jobs.rows, jobs.lda, jobs.ldb, jobs.k2, jobs.out_w, jobs.out_b, gw_ws, gw_floats, st);
+    RC(launch_grad_weights(jobs.n, jobs.a, jobs.b, jobs.rows, jobs.lda, jobs.ldb, jobs.k2, jobs.out_w, jobs.out_b, gw_ws, gw_floats, st));
+    if (frm && src_rowptr && c.e > 0) {           // assemble dW1 of the factorised message_net_1 from its two node-sized products
+        const int kf = H + tw + 1 + nv, kq = H + tw + 1;
+        hipLaunchKernelGGL(combine_w1_kernel, dim3(grid_for((long)H * c.kmsg)), dim3(256), 0, st, bm.t1, bm.t2, kf, kq, c.kmsg, tw, grads_main[0]);
+        if (gated) hipLaunchKernelGGL(combine_w1_kernel, dim3(grid_for((long)H * c.kmsg)), dim3(256), 0, st, bg.t1, bg.t2, kf, kq, c.kmsg, tw, grads_gate[0]);
+        RC(check_launch("combine_w1_kernel"));
+    }
+    return MSMP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
