@@ -316,7 +316,8 @@ int msmp_lem_encoder_nodes_f32(const float* u, const float* pos_x, const float* 
  * ------------------------------------------------------------------------------------------- */
 /* LEMFunction.forward (:287-295): the recurrence of msmp_lem_encoder_f32 (no lemoutput_mlp, exact-fp32 MFMA) that also
  * saves what the backward needs, as the reference saves all_X / all_X2 / all_multi_scales / all_lin_new_z_state:
- * saved [6][N][T][128] floats (msmp_lem_saved_floats) = dt*sigmoid(g2), tanh(g3), dt*sigmoid(g1), tanh(lin), y_t, z_t.
+ * saved [6][N][T][128] floats (msmp_lem_saved_floats) = dt*sigmoid(g2), tanh(g3), dt*sigmoid(g1), tanh(lin), y_{t-1} (the state
+ * entering step t; y0 at t = 0), z_t.
  * xin / packed as for msmp_lem_encoder_f32; y_out [N,128] = all_y[-1]. */
 int64_t msmp_lem_saved_floats(int64_t n_nodes, int t_len);
 /* y0 / z0 [N,128]: the initial states (LEMcuda.forward's `states`, :325-332; both NULL = zeros); z_out [N,128] = all_z[-1] (or
@@ -393,6 +394,12 @@ int64_t msmp_grad_weights_workspace_floats(int n_jobs, const int64_t* rows, cons
 int msmp_grad_weights_f32(int n_jobs, const float* const* a, const float* const* b, const int64_t* rows, const int* lda,
                           const int* ldb, const int* k2, float* const* out_w, float* const* out_b, float* workspace,
                           int64_t workspace_floats, msmp_stream_t stream);
+/* The same with B given as the virtual column concatenation [b | b2] (columns >= ksplit[i] of job i come from b2[i], row stride ldb2[i]):
+ * the LEM weight gradients multiply d gates with [y_{t-1} ; x_t] and [z_t ; x_t], which live in two tensors (lem_cuda.backward,
+ * experiments/models_gnn.py:296-302); b2[i] == NULL: the job is as in msmp_grad_weights_f32. */
+int msmp_grad_weights_cat_f32(int n_jobs, const float* const* a, const float* const* b, const float* const* b2, const int64_t* rows,
+                              const int* lda, const int* ldb, const int* ldb2, const int* ksplit, const int* k2, float* const* out_w,
+                              float* const* out_b, float* workspace, int64_t workspace_floats, msmp_stream_t stream);
 
 /* Two-layer node MLP  out = Swish(W2 Swish(W1 x + b1) + b2)  in one launch: the `embedding_mlp` encoder of the LEM-free
  * solver classes (experiments/models_gnn.py:196-201 called at :269-270; models_gnn2D.py:66-71 called at :119-120).

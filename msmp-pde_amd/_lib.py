@@ -71,6 +71,7 @@ SIGNATURES = {
     'msmp_gate_blend_bwd_f32': (c_int, [c_void_p] * 5 + [c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'msmp_grad_weights_workspace_floats': (c_int64, [c_int, c_void_p, c_void_p]),
     'msmp_grad_weights_f32': (c_int, [c_int] + [c_void_p] * 9 + [c_int64, c_void_p]),
+    'msmp_grad_weights_cat_f32': (c_int, [c_int] + [c_void_p] * 12 + [c_int64, c_void_p]),
     'msmp_mp_layer_bwd_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
     'msmp_mp_layer_bwd_f32': (c_int, [c_void_p] * 11 + [c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -102,25 +102,35 @@ def _head_recompute(h, u, pos, variables, gs, p):
 
 def grad_weights(pairs):
     """[(A [R,128] = dL/d pre-activation, B [R,k2] = the linear layer's input; row-strided views are fine)] -> [dW [128,k2], db [128], ...] through
-    msmp_grad_weights_f32 (all pairs in one call; row-split exact-fp32 MFMA partials, deterministic)."""
+    msmp_grad_weights_f32 (all pairs in one call; row-split fp32-exact MFMA partials, deterministic).  A pair may be a triple
+    (A, B1, B2): B is then the column concatenation [B1 | B2] WITHOUT being materialised (msmp_grad_weights_cat_f32)."""
     import ctypes
     L = lib()
     n = len(pairs)
-    a = [x if x.stride(1) == 1 else x.contiguous() for x, _ in pairs]
-    b = [y if y.stride(1) == 1 else y.contiguous() for _, y in pairs]
+    fix = lambda t: t if t.stride(1) == 1 else t.contiguous()
+    a = [fix(p[0]) for p in pairs]
+    b = [fix(p[1]) for p in pairs]
+    b2 = [fix(p[2]) if len(p) > 2 else None for p in pairs]
+    kk = [b[i].shape[1] + (b2[i].shape[1] if b2[i] is not None else 0) for i in range(n)]
     rows = (ctypes.c_int64 * n)(*[x.shape[0] for x in a])
-    k2 = (ctypes.c_int * n)(*[y.shape[1] for y in b])
+    k2 = (ctypes.c_int * n)(*kk)
     lda = (ctypes.c_int * n)(*[x.stride(0) for x in a])
     ldb = (ctypes.c_int * n)(*[y.stride(0) for y in b])
-    out_w = [torch.empty(a[i].shape[1], b[i].shape[1], dtype=torch.float32, device=a[i].device) for i in range(n)]
+    out_w = [torch.empty(a[i].shape[1], kk[i], dtype=torch.float32, device=a[i].device) for i in range(n)]
     out_b = [torch.empty(a[i].shape[1], dtype=torch.float32, device=a[i].device) for i in range(n)]
     ws_floats = L.msmp_grad_weights_workspace_floats(n, rows, k2)
     if ws_floats < 0:
         raise ValueError('grad_weights: unsupported shapes')
     ws = torch.empty(ws_floats, dtype=torch.float32, device=a[0].device)
-    vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
-    check(L.msmp_grad_weights_f32(n, vp(a), vp(b), rows, lda, ldb, k2, vp(out_w), vp(out_b), ptr(ws), ws_floats, current_stream()),
-          'msmp_grad_weights_f32')
+    vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in ts])
+    if any(t is not None for t in b2):
+        ldb2 = (ctypes.c_int * n)(*[t.stride(0) if t is not None else 0 for t in b2])
+        ksplit = (ctypes.c_int * n)(*[b[i].shape[1] if b2[i] is not None else 0 for i in range(n)])
+        check(L.msmp_grad_weights_cat_f32(n, vp(a), vp(b), vp(b2), rows, lda, ldb, ldb2, ksplit, k2, vp(out_w), vp(out_b), ptr(ws), ws_floats,
+                                          current_stream()), 'msmp_grad_weights_cat_f32')
+    else:
+        check(L.msmp_grad_weights_f32(n, vp(a), vp(b), rows, lda, ldb, k2, vp(out_w), vp(out_b), ptr(ws), ws_floats, current_stream()),
+              'msmp_grad_weights_f32')
     res = []
     for w, bias in zip(out_w, out_b):
         res += [w, bias]

@@ -18,7 +18,7 @@
 // Both kernels keep the carried tensors in accumulator layout for all T steps (one node per lane, channel tile per wave) and
 // multiply on the bf16 matrix pipe with fp32-exact products (three-way bf16 split, "workgroup shape" below); the backward
 // consumes chunks of the TRANSPOSED recurrent blocks (msmp_pack_lem_bwd_f32).  Saved tensors are
-// node-major [6][N][T][128] (a2, c, a1, d, y', z'), so each is directly the row matrix of the weight-gradient GEMMs.
+// node-major [6][N][T][128] (a2, c, a1, d, y_{t-1}, z'), so each is directly the row matrix of the weight-gradient GEMMs.
 #include "lem_layout.h"
 
 namespace msmp {
@@ -192,7 +192,11 @@ __global__ __launch_bounds__(256, 2) void lem_train_fwd_kernel(LemTrainArgs a) {
             for (int f = 0; f < 2 * NS; ++f) x[X][f] = xrow[X][t * (2 * NS) + f];
 
 #pragma unroll
-        for (int X = 0; X < LEM_NX; ++X) tile_init<NS>(a, 1, ct, lane, hh, x[X], g[X]);          // g2 -> a2            (published: y)
+        for (int X = 0; X < LEM_NX; ++X) {
+            // y_{t-1}, the state ENTERING the step: what the backward and the weight gradients ([y_{t-1} ; x_t] rows) read
+            if (live[X] && a.saved) tile_store(srow[X] + (size_t)t * H + SV_Y * plane, ct, y[X]);
+            tile_init<NS>(a, 1, ct, lane, hh, x[X], g[X]);                                 // g2 -> a2            (published: y)
+        }
         LEM_B3_GROUP(chunks, g, 0, 4)
 #pragma unroll
         for (int X = 0; X < LEM_NX; ++X) {
@@ -235,10 +239,7 @@ __global__ __launch_bounds__(256, 2) void lem_train_fwd_kernel(LemTrainArgs a) {
                 acc[X][r] = tanhf_(acc[X][r]);
                 y[X][r] = (1.0f - g[X][r]) * y[X][r] + g[X][r] * acc[X][r];
             }
-            if (live[X] && a.saved) {
-                tile_store(srow[X] + (size_t)t * H + SV_D * plane, ct, acc[X]);
-                tile_store(srow[X] + (size_t)t * H + SV_Y * plane, ct, y[X]);
-            }
+            if (live[X] && a.saved) tile_store(srow[X] + (size_t)t * H + SV_D * plane, ct, acc[X]);
             publish_b3(xf + (size_t)X * XF_TILE_U4, ct, lane, y[X]);
         }
         __syncthreads();
@@ -299,12 +300,7 @@ __global__ __launch_bounds__(256, 2) void lem_bptt_kernel(LemBwdArgs a) {
             f32x16 a1, d, yp;
             tile_load(st + SV_A1 * plane, ct, a1);
             tile_load(st + SV_D * plane, ct, d);
-            if (t > 0) tile_load(st - H + SV_Y * plane, ct, yp);
-            else if (a.y0) tile_load(a.y0 + (size_t)nc[X] * H + 4 * hh, ct, yp);
-            else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) yp[r] = 0.f;
-            }
+            tile_load(st + SV_Y * plane, ct, yp);              // y_{t-1} (the forward saved the state entering the step)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float gr = dy[X][r];

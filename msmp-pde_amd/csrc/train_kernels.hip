@@ -197,12 +197,14 @@ constexpr int GW_MAX_JOBS = 10;
 constexpr int GW_MAX_UNITS = 2 * GW_MAX_JOBS;       // a job of more than 160 columns is two column groups
 struct GradWeightJob {
     const float* a;      // [rows, lda], columns 0..127 used
-    const float* b;      // [rows, ldb], columns 0..k2-1 used
+    const float* b;      // [rows, ldb], columns 0..k2-1 used (0..ksplit-1 when b2 is given)
+    const float* b2;     // optional second matrix [rows, ldb2]: column c >= ksplit of the virtual B = [b | b2] is b2's column c - ksplit
     float* out_w;        // [128, k2]
     float* out_b;        // [128]
     float* partial;      // [splits][128][ldp]
     int rows, lda, ldb, k2, ldp, rows_per_split, splits, first_block;
     int c0;              // first column of B of this unit's group (0 or 160)
+    int ldb2, ksplit;
 };
 struct GradWeightArgs {
     GradWeightJob job[GW_MAX_JOBS];       // the reduction's view: one entry per job
@@ -226,13 +228,13 @@ struct GwRegs {
     float a[8], b[8], b4[8];
 };
 template <bool FULL>
-__device__ __forceinline__ void gw_load(const GradWeightJob& j, const float* acol, const float* bcol, const float* bcol4, bool mine4, int rbase,
-                                        int rlim, GwRegs& r) {
+__device__ __forceinline__ void gw_load(const GradWeightJob& j, const float* acol, const float* bcol, int bld, const float* bcol4, int bld4, bool mine4,
+                                        int rbase, int rlim, GwRegs& r) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const size_t row = FULL ? rbase + i : rbase + min(i, max(rlim - 1, 0));
         const bool in = FULL || i < rlim;
-        const float va = acol[row * j.lda], vb = bcol[row * j.ldb];
+        const float va = acol[row * j.lda], vb = bcol[row * bld];
         r.a[i] = in ? va : 0.f;
         r.b[i] = in ? vb : 0.f;
     }
@@ -240,7 +242,7 @@ __device__ __forceinline__ void gw_load(const GradWeightJob& j, const float* aco
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const size_t row = FULL ? rbase + i : rbase + min(i, max(rlim - 1, 0));
-            const float v = bcol4[row * j.ldb];
+            const float v = bcol4[row * bld4];
             r.b4[i] = FULL || i < rlim ? v : 0.f;
         }
     }
@@ -277,22 +279,25 @@ __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int spl
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int r0 = split * j.rows_per_split, r1 = min(r0 + j.rows_per_split, j.rows);
     const float* acol = j.a + 32 * wave + m;
-    auto colptr = [&](int t, float& keep, float& ones) {
+    auto colptr = [&](int t, float& keep, float& ones, int& ld) {
         const int c = j.c0 + 32 * t + m;
         keep = c < j.k2 ? 1.0f : 0.f;
         ones = c == j.k2 ? 1.0f : 0.f;
-        return j.b + (c < j.k2 ? c : 0);
+        const bool second = j.b2 != nullptr && c >= j.ksplit && c < j.k2;      // the virtual concatenation [b | b2]
+        ld = second ? j.ldb2 : j.ldb;
+        return second ? j.b2 + (c - j.ksplit) : j.b + (c < j.k2 ? c : 0);
     };
     float keep, ones, keep4, ones4;
-    const float* bcol = colptr(wave, keep, ones);
-    const float* bcol4 = colptr(4, keep4, ones4);
+    int bld, bld4;
+    const float* bcol = colptr(wave, keep, ones, bld);
+    const float* bcol4 = colptr(4, keep4, ones4, bld4);
     const int n_blocks = (r1 - r0 + 15) / 16;            // the last one may be ragged: it takes the predicated loads
     const int n_full = (r1 - r0) / 16;
     GwRegs cur, nxt;
     auto load_block = [&](int blk, GwRegs& dst) {
         const int rb = r0 + 16 * blk + 8 * kk;
-        if (blk < n_full) gw_load<true>(j, acol, bcol, bcol4, (blk & 3) == wave, rb, 8, dst);
-        else gw_load<false>(j, acol, bcol, bcol4, (blk & 3) == wave, min(rb, r1 - 1), r1 - rb, dst);
+        if (blk < n_full) gw_load<true>(j, acol, bcol, bld, bcol4, bld4, (blk & 3) == wave, rb, 8, dst);
+        else gw_load<false>(j, acol, bcol, bld, bcol4, bld4, (blk & 3) == wave, min(rb, r1 - 1), r1 - rb, dst);
     };
     if (n_blocks > 0) load_block(0, cur);
     __builtin_amdgcn_sched_barrier(0);
@@ -369,18 +374,21 @@ namespace msmp {
 // launches of msmp_grad_weights_f32 on validated arguments (also used by the layer backward below)
 static int launch_grad_weights(int n_jobs, const float* const* a, const float* const* b, const int64_t* rows, const int* lda,
                                const int* ldb, const int* k2, float* const* out_w, float* const* out_b, float* workspace,
-                               int64_t workspace_floats, hipStream_t stream) {
+                               int64_t workspace_floats, hipStream_t stream, const float* const* b2 = nullptr, const int* ldb2 = nullptr,
+                               const int* ksplit = nullptr) {
     GradWeightArgs args;
     args.n_jobs = n_jobs;
     int64_t used = 0;
     int blocks = 0, max_w = 0, nu = 0;
     for (int i = 0; i < n_jobs; ++i) {
         MSMP_REQUIRE(a[i] && b[i] && out_w[i] && out_b[i], MSMP_ERR_ARG, "msmp_grad_weights_f32: null pointer in job %d", i);
-        MSMP_REQUIRE(rows[i] >= 1 && rows[i] < (1L << 31) && k2[i] >= 1 && ldb[i] >= k2[i] && lda[i] >= H, MSMP_ERR_ARG, "msmp_grad_weights_f32: bad sizes in job %d", i);
+        MSMP_REQUIRE(rows[i] >= 1 && rows[i] < (1L << 31) && k2[i] >= 1 && (ldb[i] >= k2[i] || (b2 && b2[i])) && lda[i] >= H, MSMP_ERR_ARG, "msmp_grad_weights_f32: bad sizes in job %d", i);
         const int nt = gw_tiles(k2[i]);
         MSMP_REQUIRE(nt > 0, MSMP_ERR_UNSUPPORTED, "msmp_grad_weights_f32: k2=%d > 319", k2[i]);
         GradWeightJob& j = args.job[i];
         j.a = a[i]; j.b = b[i]; j.out_w = out_w[i]; j.out_b = out_b[i]; j.partial = workspace + used;
+        j.b2 = b2 ? b2[i] : nullptr; j.ldb2 = j.b2 ? ldb2[i] : 0; j.ksplit = j.b2 ? ksplit[i] : 0;
+        MSMP_REQUIRE(!j.b2 || (j.ksplit >= 1 && j.ksplit < k2[i] && j.ldb2 >= k2[i] - j.ksplit && ldb[i] >= j.ksplit), MSMP_ERR_ARG, "msmp_grad_weights_f32: bad split of job %d", i);
         j.rows = (int)rows[i]; j.lda = lda[i]; j.ldb = ldb[i]; j.k2 = k2[i]; j.ldp = 32 * nt;
         j.rows_per_split = gw_rows_per_split(rows[i]);
         j.splits = (j.rows + j.rows_per_split - 1) / j.rows_per_split;
@@ -409,6 +417,14 @@ extern "C" int msmp_grad_weights_f32(int n_jobs, const float* const* a, const fl
     MSMP_REQUIRE(n_jobs >= 1 && n_jobs <= GW_MAX_JOBS, MSMP_ERR_ARG, "msmp_grad_weights_f32: n_jobs=%d not in 1..%d", n_jobs, GW_MAX_JOBS);
     MSMP_REQUIRE(a && b && rows && lda && ldb && k2 && out_w && out_b && workspace, MSMP_ERR_ARG, "msmp_grad_weights_f32: null pointer");
     return launch_grad_weights(n_jobs, a, b, rows, lda, ldb, k2, out_w, out_b, workspace, workspace_floats, (hipStream_t)stream);
+}
+
+extern "C" int msmp_grad_weights_cat_f32(int n_jobs, const float* const* a, const float* const* b, const float* const* b2, const int64_t* rows,
+                                         const int* lda, const int* ldb, const int* ldb2, const int* ksplit, const int* k2, float* const* out_w,
+                                         float* const* out_b, float* workspace, int64_t workspace_floats, msmp_stream_t stream) {
+    MSMP_REQUIRE(n_jobs >= 1 && n_jobs <= GW_MAX_JOBS, MSMP_ERR_ARG, "msmp_grad_weights_cat_f32: n_jobs=%d not in 1..%d", n_jobs, GW_MAX_JOBS);
+    MSMP_REQUIRE(a && b && b2 && rows && lda && ldb && ldb2 && ksplit && k2 && out_w && out_b && workspace, MSMP_ERR_ARG, "msmp_grad_weights_cat_f32: null pointer");
+    return launch_grad_weights(n_jobs, a, b, rows, lda, ldb, k2, out_w, out_b, workspace, workspace_floats, (hipStream_t)stream, b2, ldb2, ksplit);
 }
 
 // ==============================================================================================

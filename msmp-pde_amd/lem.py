@@ -109,14 +109,10 @@ class _LEMTrainFunction(torch.autograd.Function):
               'msmp_lem_train_bwd_f32')
         planes = saved.view(6, n, t_len, nh)
         xs = x.view(n * t_len, stride)[:, :ctx.ninp]
-        if y0 is None:
-            y_prev = torch.nn.functional.pad(planes[4][:, :-1], (0, 0, 1, 0)).reshape(n * t_len, nh)     # y_{t-1}, y_{-1} = 0
-        else:
-            y_prev = torch.cat((y0[:, None, :], planes[4][:, :-1]), 1).reshape(n * t_len, nh)            # y_{-1} = y0
-        yx = torch.cat((y_prev, xs), 1)
-        zx = torch.cat((planes[5].reshape(n * t_len, nh), xs), 1)
-        from .autograd import grad_weights          # weight / bias gradients: sums over the N*T rows (msmp_grad_weights_f32)
-        g = grad_weights([(dg[:, :nh], yx), (dg[:, nh:2 * nh], yx), (dg[:, 2 * nh:3 * nh], yx), (dg[:, 3 * nh:], zx)])
+        y_prev = planes[4].reshape(n * t_len, nh)            # the forward saves y_{t-1} (y0 at t = 0): the rows of [y_{t-1} ; x_t]
+        z_new = planes[5].reshape(n * t_len, nh)
+        from .autograd import grad_weights          # weight / bias gradients: sums over the N*T rows; [state | x_t] is never materialised
+        g = grad_weights([(dg[:, :nh], y_prev, xs), (dg[:, nh:2 * nh], y_prev, xs), (dg[:, 2 * nh:3 * nh], y_prev, xs), (dg[:, 3 * nh:], z_new, xs)])
         d_w, d_b = torch.cat(g[0:6:2], 0), torch.cat(g[1:6:2], 0)
         return None, None, d_w.to(weights.dtype), g[6].to(weights_lin_z.dtype), d_b, g[7], None, None
 
