@@ -347,12 +347,15 @@ __global__ __launch_bounds__(256) void grad_weight_reduce_kernel(GradWeightArgs 
 }
 
 static int gw_tiles(int k2) { const int t = (k2 + 1 + 31) / 32; return t <= 5 ? 5 : t <= 9 ? 9 : t <= 10 ? 10 : -1; }
-// rows per workgroup: 128, more once a pair would exceed 512 splits (the partial products, splits x 128 x 32 nt floats, are
-// written and re-read by the reduction).  Measured per training iteration with limits 128 / 256 / 512 (E2 MSMP-PDE): batch 16
+// rows per workgroup: 128, more once a pair would exceed its split limit (the partial products, splits x 128 x 32 nt floats, are
+// written and re-read by the reduction).  Round 1 measured limits 128 / 256 / 512 with the fp32 kernel (E2 MSMP-PDE): batch 16
 // 7.1 / 7.0 / 6.3 ms (the LEM pairs have 40 000 rows), batch 128 15.0 / 14.9 / 14.9, batch 512 51.1 / 49.7 / 48.9.
 static int gw_rows_per_split(int64_t rows) {
+    // small jobs keep up to 512 splits (they need the parallelism); large ones 128 (measured at batch 512, ms per iteration, cap
+    // 512 / 256 / 128 / 64: 24.0 / 23.7 / 23.7 / 25.2: fewer partials to write and re-read until the splits no longer fill the chip)
+    const int64_t lim = rows > 32768 ? 128 : 512;
     int64_t rps = 128;
-    while ((rows + rps - 1) / rps > 512) rps *= 2;
+    if ((rows + rps - 1) / rps > lim) rps = ((rows + lim - 1) / lim + 15) / 16 * 16;
     return (int)rps;
 }
 
