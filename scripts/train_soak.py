@@ -10,6 +10,9 @@ from msmp_pde_amd.lem import LEM
 from msmp_pde_amd.synthetic import make_case, EXPERIMENTS
 from msmp_pde_amd.train import training_step
 name = sys.argv[1] if len(sys.argv) > 1 else 'MSMP-PDE'
+if '--own-gemm' in sys.argv:        # force the library's own row GEMMs + the factorised message_net_1 backward (default only from 32 768 edges on)
+    sys.argv.remove('--own-gemm')
+    mp.lib().msmp_tune(b'bwd_gemm', 2)
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 curves = {}
 for path in (2, 0, 20, 10):        # 20 / 10: the same two paths once more (run-to-run spread of each: atomics in both)
