@@ -52,8 +52,28 @@ extern "C" {
 
 typedef void* msmp_stream_t;
 
+/* ABI version: 300 = round 3 (msmp_last_status, msmp_tiles_t checked on every entry point that takes one).  Bumped whenever a
+ * prototype or a blob layout changes; the ctypes host refuses a library whose version is not the one it was written for. */
+#define MSMP_ABI_VERSION 300
 int msmp_version(void);
 const char* msmp_last_error(void);
+
+/* Sticky range status of the fp16-split matrix path ("Range").  The default kernels carry node rows scaled
+ * by 2^8 (saturating at +-65504, i.e. |x| <= 255) and hidden activations scaled by 2^6 (|x| < 1023, beyond that fp16 inf); the
+ * reference has no such limit.  Kernels OR a bit into a host-visible word when a value leaves that range, so wrong-but-finite or
+ * NaN output never goes unnoticed:
+ *   MSMP_STATUS_INPUT_RANGE     an input feature (u, pos / L, a variables column) had |x| > 255 or was not finite
+ *                               (msmp_prepare_nodes, msmp_pack_node_features_f32);
+ *   MSMP_STATUS_NODE_SATURATED  a hidden-state row staged by the tile kernel, a row of the blend, or an aggregate written by a
+ *                               message kernel had |x| > 255 (or was NaN: an activation above 1023 overflowed upstream);
+ *   MSMP_STATUS_NONFINITE       the InstanceNorm statistics of a graph were not finite (node tail).
+ * msmp_last_status reads the word WITHOUT synchronising (it lives in host-mapped memory the kernels update with system-scope
+ * atomics: what it returns covers all work that has completed; after a stream synchronise, all work issued).  reset != 0 clears
+ * it.  Remedy: rescale the data, or run the exact-fp32 kernels (msmp_tune("split", 0): no range limit). */
+#define MSMP_STATUS_INPUT_RANGE    1
+#define MSMP_STATUS_NODE_SATURATED 2
+#define MSMP_STATUS_NONFINITE      4
+int msmp_last_status(int* flags_out, int reset);
 /* Knobs for A/B measurements and validation (not part of the data contract):
  *   "split"   1 (default): the GEMMs of the node / edge / LEM kernels run on the fp16 matrix pipe with a 2-way
  *             fp16 split of both operands (fp32-class accuracy); 0: the fp32-MFMA kernels.

@@ -3,7 +3,8 @@
 Host-side mirror of the reference's module interface over the C-ABI library libmsmp_pde.so
 (include/msmp_pde.h).  See DESIGN.md.  Import as `msmp_pde_amd` (alias module at the repo root).
 """
-from ._lib import lib, MsmpError, LIB_PATH, invalidate_packed_weights         # noqa: F401
+from ._lib import (lib, MsmpError, LIB_PATH, invalidate_packed_weights, last_status, MsmpRangeWarning,         # noqa: F401
+                   MSMP_STATUS_INPUT_RANGE, MSMP_STATUS_NODE_SATURATED, MSMP_STATUS_NONFINITE)
 from .pde import CE, WE, AD                                                   # noqa: F401
 from .graph import Data, GraphCreator, GraphStructure, structure_of, radius_graph, knn_graph   # noqa: F401
 from .layers import Swish, GNN_Layer, GNN_LayerLin, mp_layer                  # noqa: F401

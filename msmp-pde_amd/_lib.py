@@ -20,11 +20,14 @@ MSMP_LAYER_LIN = 1
 MSMP_ERR_UNSUPPORTED = -2
 MSMP_MAX_VARS = 8
 HIDDEN = 128
+MSMP_ABI_VERSION = 300          # include/msmp_pde.h: the library must report exactly this (argument lists changed in rounds 2 and 3)
+MSMP_STATUS_INPUT_RANGE, MSMP_STATUS_NODE_SATURATED, MSMP_STATUS_NONFINITE = 1, 2, 4
 
 # name -> (restype, argtypes); must list every symbol include/msmp_pde.h declares
 SIGNATURES = {
     'msmp_version': (c_int, []),
     'msmp_last_error': (c_char_p, []),
+    'msmp_last_status': (c_int, [ctypes.POINTER(c_int), c_int]),
     'msmp_tune': (c_int, [c_char_p, c_int]),
     'msmp_tune_query': (c_int, [c_char_p]),
     'msmp_packed_layer_floats': (c_int64, [c_int, c_int]),
@@ -109,6 +112,9 @@ def lib():
             fn = getattr(handle, name)        # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if handle.msmp_version() != MSMP_ABI_VERSION:
+            raise MsmpError(f'{LIB_PATH} reports ABI version {handle.msmp_version()}, this binding was written for {MSMP_ABI_VERSION}: '
+                            'rebuild it with `python msmp-pde_amd/build.py`')
         _lib = handle
     return _lib
 
@@ -169,3 +175,42 @@ def timing_read(kernel):
     n, ms = c_int64(0), c_double(0.0)
     check(lib().msmp_timing_read(kernel, ctypes.byref(n), ctypes.byref(ms)), 'msmp_timing_read')
     return n.value, ms.value
+
+
+# ---- range status of the fp16-split path (msmp_last_status) ----------------------------------------------------------------
+class MsmpRangeWarning(RuntimeWarning):
+    """A value left the range the default (fp16-split) kernels represent: results are saturated or not finite."""
+
+
+_STATUS_TEXT = {
+    MSMP_STATUS_INPUT_RANGE: 'an input feature (u, pos / L or a variables column) has |x| > 255 or is not finite',
+    MSMP_STATUS_NODE_SATURATED: 'a hidden-state / aggregate row has |x| > 255 or is NaN (saturated at 255.87 in the GEMM operands)',
+    MSMP_STATUS_NONFINITE: 'the InstanceNorm statistics of a graph are not finite (an activation above 1023 overflowed fp16 upstream)',
+}
+_status_seen = [0]
+
+
+def last_status(reset=False):
+    """Sticky range flags (MSMP_STATUS_*) of all kernel work that has COMPLETED so far; no device synchronisation."""
+    flags = c_int(0)
+    check(lib().msmp_last_status(ctypes.byref(flags), int(bool(reset))), 'msmp_last_status')
+    if reset:
+        _status_seen[0] = 0
+    return flags.value
+
+
+def status_check():
+    """Called at the top of every solver forward: one host read.  New flags -> MsmpRangeWarning (MSMP_STRICT_RANGE=1 in the
+    environment: MsmpError).  The flags stay set until last_status(reset=True)."""
+    flags = last_status()
+    new = flags & ~_status_seen[0]
+    if new:
+        _status_seen[0] |= new
+        msg = ('msmp_pde_amd: the fp16-split matrix path left its range: ' + '; '.join(t for b, t in _STATUS_TEXT.items() if new & b)
+               + ".  Outputs since then are saturated / not finite.  Rescale the data or select the exact-fp32 kernels with "
+                 "lib().msmp_tune(b'split', 0); clear with last_status(reset=True).")
+        if os.environ.get('MSMP_STRICT_RANGE') == '1':
+            raise MsmpError(msg)
+        import warnings
+        warnings.warn(msg, MsmpRangeWarning, stacklevel=3)
+    return flags

@@ -9,7 +9,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 VARIANT = os.environ.get('MSMP_TILE_VARIANT', '')      # kernel A/B experiments (-DMSMP_TILE_VARIANT=N): separate library libmsmp_pde_v<N>.so
 PRECISE = os.environ.get('MSMP_PRECISE', '') == '1'     # diagnostic build: libm / correctly rounded activations (msmp_common.h)
-LIB = os.path.join(PKG, 'libmsmp_pde_precise.so' if PRECISE else ('libmsmp_pde_prof.so' if os.environ.get('MSMP_PROF') else (f'libmsmp_pde_v{VARIANT}.so' if VARIANT else 'libmsmp_pde.so')))
+LOLO = os.environ.get('MSMP_LOLO', '')                 # diagnostic build: fourth product lo*lo of the fp16 split (mfma_tiles.h), level 1 | 2 -> libmsmp_pde_lolo<N>.so
+LIB = os.path.join(PKG, f'libmsmp_pde_lolo{LOLO}.so' if LOLO else 'libmsmp_pde_precise.so' if PRECISE else ('libmsmp_pde_prof.so' if os.environ.get('MSMP_PROF') else (f'libmsmp_pde_v{VARIANT}.so' if VARIANT else 'libmsmp_pde.so')))
 
 SOURCES = {  # file -> extra flags
     'mlp_kernels.hip': [],
@@ -24,7 +25,7 @@ SOURCES = {  # file -> extra flags
     'graph_kernels.hip': ['-ffp-contract=off'],   # float64 distance compares must round like the host's
 }
 PROF = {'tile': ['-DMSMP_PROF_TILE=1'], '1': ['-DMSMP_PROF=1'], 'edge': ['-DMSMP_PROF=1', '-DMSMP_PROF_EDGE=1'], 'proj': ['-DMSMP_PROF=1', '-DMSMP_PROF_PROJ=1']}.get(os.environ.get('MSMP_PROF', ''), [])     # phase counters in the tail kernel (scripts/prof_tail.py)
-COMMON = PROF + ([f'-DMSMP_TILE_VARIANT={VARIANT}'] if VARIANT else []) + (['-DMSMP_PRECISE_ACT=1'] if PRECISE else []) + ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
+COMMON = PROF + ([f'-DMSMP_LOLO={LOLO}'] if LOLO else []) + ([f'-DMSMP_TILE_VARIANT={VARIANT}'] if VARIANT else []) + (['-DMSMP_PRECISE_ACT=1'] if PRECISE else []) + ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
           '-fvisibility=hidden', '-fvisibility-inlines-hidden',
           '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
 
@@ -43,7 +44,7 @@ def build(force=False, verbose=False):
     objs = []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace('.hip', '.precise.o' if PRECISE else ('.prof.o' if os.environ.get('MSMP_PROF') else (f'.v{VARIANT}.o' if VARIANT else '.o'))))
+        o = os.path.join(CSRC, src.replace('.hip', f'.lolo{LOLO}.o' if LOLO else '.precise.o' if PRECISE else ('.prof.o' if os.environ.get('MSMP_PROF') else (f'.v{VARIANT}.o' if VARIANT else '.o'))))
         if force or _stale(o, [s] + headers):
             cmd = [hipcc] + COMMON + extra + ['-c', s, '-o', o]
             if verbose:

@@ -215,7 +215,7 @@ __global__ void pack_layer_split_kernel(PackArgs a) {
 // reproducible); loads are independent of each other, so the wave keeps `deg` rows in flight.
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scatter_mean_kernel(const float* __restrict__ msg, const int* __restrict__ rowptr,
-                                                           long n_nodes, float* __restrict__ agg) {
+                                                           long n_nodes, float* __restrict__ agg, int* status) {
     const int sub = threadIdx.x & 31;
     const long node = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
     if (node >= n_nodes) return;
@@ -229,7 +229,9 @@ __global__ __launch_bounds__(256) void scatter_mean_kernel(const float* __restri
     }
     for (; r < r1; ++r, p += H / 4) s += p[0];
     const float inv = 1.0f / (float)max(r1 - r0, 1);
-    reinterpret_cast<f32x4*>(agg)[(size_t)node * (H / 4) + sub] = s * inv;
+    const f32x4 res = s * inv;
+    reinterpret_cast<f32x4*>(agg)[(size_t)node * (H / 4) + sub] = res;
+    if (out_of_range(res)) status_raise(status, MSMP_STATUS_NODE_SATURATED);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -391,7 +393,57 @@ extern "C" int msmp_timing_read(int kernel, int64_t* launches_out, double* total
     return MSMP_OK;
 }
 
-extern "C" int msmp_version(void) { return 100; }
+// ---- sticky range status ----------------------------------------------------------------------------------------------
+// One int in host-mapped (fine-grained) memory: kernels reach it with system-scope atomics only when something is out of range,
+// the host reads it like any variable.  If the mapping cannot be made the word lives in device memory and msmp_last_status pays
+// a blocking copy.
+static int* g_status_host = nullptr;
+static int* g_status_dev = nullptr;
+static int g_status_mode = 0;       // 0 not created, 1 host-mapped, 2 device memory, -1 unavailable
+namespace msmp {
+int* status_ptr() {
+    if (g_status_mode == 0) {
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+            hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            g_status_host = static_cast<int*>(hp);
+            *g_status_host = 0;
+            g_status_dev = static_cast<int*>(dp);
+            g_status_mode = 1;
+        } else {
+            (void)hipGetLastError();
+            if (hipMalloc(&dp, sizeof(int)) == hipSuccess && hipMemset(dp, 0, sizeof(int)) == hipSuccess) {
+                g_status_dev = static_cast<int*>(dp);
+                g_status_mode = 2;
+            } else {
+                (void)hipGetLastError();
+                g_status_mode = -1;
+            }
+        }
+    }
+    return g_status_dev;
+}
+}  // namespace msmp
+
+extern "C" int msmp_last_status(int* flags_out, int reset) {
+    MSMP_REQUIRE(flags_out, MSMP_ERR_ARG, "msmp_last_status: null pointer");
+    int* dp = status_ptr();
+    *flags_out = 0;
+    if (g_status_mode == 1) {
+        *flags_out = __atomic_load_n(g_status_host, __ATOMIC_RELAXED);
+        if (reset) __atomic_store_n(g_status_host, 0, __ATOMIC_RELAXED);
+    } else if (g_status_mode == 2) {
+        hipError_t e = hipMemcpy(flags_out, dp, sizeof(int), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && reset) e = hipMemset(dp, 0, sizeof(int));
+        MSMP_REQUIRE(e == hipSuccess, MSMP_ERR_HIP, "msmp_last_status: %s", hipGetErrorString(e));
+    } else {
+        MSMP_REQUIRE(false, MSMP_ERR_HIP, "msmp_last_status: no status word (allocation failed)");
+    }
+    return MSMP_OK;
+}
+
+extern "C" int msmp_version(void) { return MSMP_ABI_VERSION; }
 extern "C" const char* msmp_last_error(void) { return g_err; }
 
 extern "C" int64_t msmp_packed_layer_floats(int tw, int nv) {
@@ -417,7 +469,7 @@ extern "C" int msmp_scatter_mean_f32(const float* msg, const int32_t* rowptr, in
     MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31), MSMP_ERR_ARG, "msmp_scatter_mean_f32: bad n_nodes");
     const unsigned grid = (unsigned)((n_nodes + 7) / 8);
     timing_begin(MSMP_K_SCATTER_MEAN, (hipStream_t)stream);
-    hipLaunchKernelGGL(scatter_mean_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, msg, rowptr, (long)n_nodes, agg_out);
+    hipLaunchKernelGGL(scatter_mean_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, msg, rowptr, (long)n_nodes, agg_out, status_ptr());
     timing_end(MSMP_K_SCATTER_MEAN, (hipStream_t)stream);
     return check_launch("scatter_mean_kernel");
 }
@@ -482,6 +534,9 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
     MSMP_REQUIRE(h && u && pos && vars && rowptr && col && tgt && graph_ptr && packed_main && h_out && workspace,
                  MSMP_ERR_ARG, "msmp_mp_layer_f32: null pointer");
     MSMP_REQUIRE(h_out != h, MSMP_ERR_ARG, "msmp_mp_layer_f32: h_out may not alias h");
+    MSMP_REQUIRE(!tiles || (tiles->tile_nodes >= 1 && (int64_t)tiles->n_tiles * tiles->tile_nodes >= n_nodes &&
+                            (int64_t)(tiles->n_tiles - 1) * tiles->tile_nodes < n_nodes),
+                 MSMP_ERR_ARG, "msmp_mp_layer_f32: tile descriptor does not cover %ld nodes", (long)n_nodes);
     const int gated = packed_gate != nullptr;
     const bool dense = (mode & MSMP_LAYER_DENSE_MESSAGE) != 0;
     mode &= ~MSMP_LAYER_DENSE_MESSAGE;

@@ -450,6 +450,7 @@ __device__ __forceinline__ void mma_chunk_split_half(const float* wl, int lane, 
         for (int i = 0; i < 2; ++i) {
             const half8 ahi = w[((s * 4 + tile0 + i) * 2 + 0) * 64];
             const half8 alo = w[((s * 4 + tile0 + i) * 2 + 1) * 64];
+            MSMP_MFMA_LOLO(2, acc[i], alo, blo[s]);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[s], acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[s], acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[s], acc[i], 0, 0, 0);
@@ -838,6 +839,8 @@ __device__ __forceinline__ void lem_ws_gemm2(const half8 (&w0)[4][2][2], const h
             }
             // three back-to-back MFMAs per accumulator: a dependent MFMA issued right behind its producer accumulates in
             // place; alternating the two accumulators made every MFMA wait for the previous write-back (2x slower)
+            MSMP_MFMA_LOLO(2, acc0, w0[kt][s][1], l0);
+            MSMP_MFMA_LOLO(2, acc1, w1[kt][s][1], l1);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][1], h0, acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][0], l0, acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][0], h0, acc0, 0, 0, 0);
@@ -978,6 +981,7 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const half8 h0 = yb[((kt * 2 + s) * 2 + 0) * 64 + lane], l0 = yb[((kt * 2 + s) * 2 + 1) * 64 + lane];
+                MSMP_MFMA_LOLO(2, acc, w[0][kt][s][1], l0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][kt][s][1], h0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][kt][s][0], l0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][kt][s][0], h0, acc, 0, 0, 0);
@@ -992,6 +996,7 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const half8 h0 = hb[((kt * 2 + s) * 2 + 0) * 64 + lane], l0 = hb[((kt * 2 + s) * 2 + 1) * 64 + lane];
+                MSMP_MFMA_LOLO(2, res, w[1][kt][s][1], l0);
                 res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][1], h0, res, 0, 0, 0);
                 res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][0], l0, res, 0, 0, 0);
                 res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][0], h0, res, 0, 0, 0);

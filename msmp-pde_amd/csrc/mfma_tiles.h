@@ -98,7 +98,14 @@ __device__ __forceinline__ void acc_init_bias(const float* __restrict__ bias, in
 //   acc order      k = 16s + 8(j >> 2) + 4h + (j & 3)      (B taken from a 32x32 accumulator: registers 8s..8s+7)
 // ------------------------------------------------------------------------------------------------
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
-constexpr int SPLIT_CHUNK_FLOATS = 4096;      // 16 KB, same footprint as an fp32 chunk
+constexpr int SPLIT_CHUNK_FLOATS = 4096;
+// Diagnostic builds (`MSMP_LOLO=1|2 python msmp-pde_amd/build.py`, never shipped): the fourth product lo_a lo_b of the split,
+// level 1 in update_net_1 / update_net_2 of the node kernels (what feeds each InstanceNorm), level 2 in every split GEMM.
+// Used by scripts/diag_lolo.py to attribute the full-depth error to the dropped term or to the 22-bit operands themselves.
+#ifndef MSMP_LOLO
+#define MSMP_LOLO 0
+#endif
+#define MSMP_MFMA_LOLO(level, acc, alo, blo) do { if (MSMP_LOLO >= (level)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, blo, acc, 0, 0, 0); } while (0)      // 16 KB, same footprint as an fp32 chunk
 
 // packed fp32 arithmetic (two values per instruction at the single-value issue cost); the compiler scalarises most
 // <2 x float> expressions, so the activation pipeline names the instructions
@@ -184,6 +191,7 @@ __device__ __forceinline__ void mma_chunk_split(const float* wl, int lane, const
             const half8 alo = w[((s * 4 + T) * 2 + 1) * 64];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
+                MSMP_MFMA_LOLO(1, acc[T][nb], alo, blo[nb][s]);
                 acc[T][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[nb][s], acc[T][nb], 0, 0, 0);
                 acc[T][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[nb][s], acc[T][nb], 0, 0, 0);
                 acc[T][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[nb][s], acc[T][nb], 0, 0, 0);

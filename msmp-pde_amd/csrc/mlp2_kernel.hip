@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_split_kernel(Mlp2Args a) {
 #pragma unroll
             for (int T = 0; T < 4; ++T) {
                 const half8 whi = w[((s * 4 + T) * 2 + 0) * 64], wlo = w[((s * 4 + T) * 2 + 1) * 64];
+                MSMP_MFMA_LOLO(2, yT[T], zlo[0][s], wlo);
                 yT[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zhi[0][s], wlo, yT[T], 0, 0, 0);
                 yT[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zlo[0][s], whi, yT[T], 0, 0, 0);
                 yT[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zhi[0][s], whi, yT[T], 0, 0, 0);

@@ -45,6 +45,7 @@ struct EdgeArgs {
     const float* Q;      // FACT: [N,128] source-side projection  W1[:, h_j] h - W1[:, u|p] [u, p]
     float* msg;          // !FUSE: [E,128] messages
     float* agg;          // FUSE:  [N,128] mean of the messages of each target
+    int* status;         // msmp_last_status word (or nullptr)
 };
 
 // B fragments of chunk `c` of the concatenated edge feature [h_i | h_j | u_i-u_j | p_i-p_j | v_i | 0...]
@@ -356,7 +357,9 @@ __device__ __forceinline__ void edge_mlp_body(const EdgeArgs& a, float* lds) {
                     for (int i = 0; i < 4; ++i) sum += v[i];
                 }
                 const float inv = 1.0f / (float)max(r1 - r0, 1);
-                *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + CPR * R + 4 * cq) = sum * inv;
+                const f32x4 res = sum * inv;
+                *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + CPR * R + 4 * cq) = res;
+                if (out_of_range(res)) status_raise(a.status, MSMP_STATUS_NODE_SATURATED);
             }
             PROF_EDGE(9);
         }
@@ -668,6 +671,7 @@ __device__ __forceinline__ void mma_chunk_split_t(const float* wl, int lane, con
         for (int T = 0; T < 4; ++T) {
             const half8 whi = w[((s * 4 + T) * 2 + 0) * 64];
             const half8 wlo = w[((s * 4 + T) * 2 + 1) * 64];
+            MSMP_MFMA_LOLO(2, acc[T], alo[0][s], wlo);
             acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0][s], wlo, acc[T], 0, 0, 0);
             acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[0][s], whi, acc[T], 0, 0, 0);
             acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0][s], whi, acc[T], 0, 0, 0);
@@ -964,6 +968,7 @@ struct TailArgs {
     const float* w4t[2];
     const float* scales[2];
     float* out;
+    int* status;             // msmp_last_status word (or nullptr)
 };
 
 // One update head, update_net_2 transposed: yT[T][r] = 2^s4 (W4 Swish(W3 [h ; agg ; vars] + b3) + b4)[channel 4 c + T]
@@ -995,7 +1000,7 @@ template <typename MidHook>
 __device__ __forceinline__ void head_compute(HeadRows& st, const float* __restrict__ h, const float* __restrict__ agg,
                                              const float* __restrict__ vars, long nc, int nv, const float* b3, const float* b4,
                                              const float* w3vh, const float* w3s, const float* w4t, const float* scales, float* lds,
-                                             int tid, int lane, int c, int hh, f32x16 (&yT)[4], MidHook mid_hook PROF_ARGS) {
+                                             int tid, int lane, int c, int hh, f32x16 (&yT)[4], MidHook mid_hook, bool center, float* zref PROF_ARGS) {
     // ACT_SCALE: the node rows and the Swish output enter the split GEMMs multiplied by 2^6, so that the fp16 low halves of small
     // activations stay normal (see tile_kernels.hip); every factor is a power of two folded into an existing constant.
     const float sc3 = scales[2] * TAIL_NODE_SCALE, inv3 = scales[6] * (TAIL_ACT_SCALE / TAIL_NODE_SCALE), sc4 = scales[3] * TAIL_ACT_SCALE;
@@ -1060,8 +1065,32 @@ __device__ __forceinline__ void head_compute(HeadRows& st, const float* __restri
 #endif
         }
 
+    // `center` (the head's output goes straight into an InstanceNorm: GNN_LayerLin, experiments/models_gnn.py:129): the norm removes
+    // every per-graph, per-channel constant, so update_net_2 is evaluated on z_n - z_ref (z_ref = the hidden units of the graph's
+    // first node) and without its bias: y_n - y_ref = W4 (z_n - z_ref).  The accumulator then carries the VARIATION of y over the
+    // graph instead of its value, and the 24 fp32 roundings of the K = 128 accumulation are relative to what the norm divides by.
+    // (scripts/diag_quant.py: with untrained weights |y| is 10-100 x its spread over a graph, and this accumulation was 90 % of a
+    // layer's error after the norm: 5.2e-7 of 5.4e-7 rms.)
+    if (center) {
+        if ((tid >> 6) == 0 && c == 0) {
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4*>(zref + 32 * T + 8 * q + 4 * hh) = f32x4{z[T][0][4 * q], z[T][0][4 * q + 1], z[T][0][4 * q + 2], z[T][0][4 * q + 3]};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(zref + 32 * T + 8 * q + 4 * hh);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) z[T][0][4 * q + m] -= rv[m];
+            }
+    }
     {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(b4 + 4 * c) * sc4;
+        const f32x4 bv = center ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(b4 + 4 * c) * sc4;
 #pragma unroll
         for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -1078,6 +1107,7 @@ __device__ __forceinline__ void head_compute(HeadRows& st, const float* __restri
 #pragma unroll
             for (int T = 0; T < 4; ++T) {
                 const half8 whi = w[((s * 4 + T) * 2 + 0) * 64], wlo = w[((s * 4 + T) * 2 + 1) * 64];
+                MSMP_MFMA_LOLO(1, yT[T], zlo[0][s], wlo);
                 yT[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zhi[0][s], wlo, yT[T], 0, 0, 0);
                 yT[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zlo[0][s], whi, yT[T], 0, 0, 0);
                 yT[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zhi[0][s], whi, yT[T], 0, 0, 0);
@@ -1109,7 +1139,7 @@ __device__ __forceinline__ void tile_t_total(const float (&v)[4], float* part, f
 
 // x <- (x - mean) / sqrt(var + eps) per channel over the graph's cnt nodes; x is in units of `unit` (a power of two)
 __device__ __forceinline__ void tile_t_instance_norm(f32x16 (&x)[4], int wave, int cnt, float unit, float eps, float* part, float* tot,
-                                                     int tid, int c, int hh) {
+                                                     int tid, int c, int hh, int* status) {
     const float inv = 1.0f / (float)max(cnt, 1);
     const bool ragged = wave * 32 + 32 > cnt;       // wave-uniform: some of this wave's 32 nodes lie past the graph
     if (ragged) {
@@ -1145,6 +1175,8 @@ __device__ __forceinline__ void tile_t_instance_norm(f32x16 (&x)[4], int wave, i
         s[T] = a0 + a1;
     }
     tile_t_total(s, part, tot, tid, wave, c, hh, m);
+    // range sentinel: an activation beyond the fp16 range upstream (|Swish| > 1023) arrives here as inf / NaN statistics
+    if (wave == 0 && !(m[0] + m[1] + m[2] + m[3] < 3.0e38f)) status_raise(status, MSMP_STATUS_NONFINITE);
 #pragma unroll
     for (int T = 0; T < 4; ++T) {
         const float f = unit * msmp_rsq(m[T] * inv * unit * unit + eps);
@@ -1172,9 +1204,9 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
     if (GATED) {
         head_rows_issue(a.h, a.agg[1], nc, hh, rows);
         head_compute(rows, a.h, a.agg[1], a.vars, nc, a.nv, a.b3[1], a.b4[1], a.w3vh[1], a.w3s[1], a.w4t[1], a.scales[1], lds, tid, lane,
-                     c, hh, tau, [&] { head_rows_issue(a.h, a.agg[0], nc, hh, rows); } PROF_PASS);
+                     c, hh, tau, [&] { head_rows_issue(a.h, a.agg[0], nc, hh, rows); }, true, tot PROF_PASS);
         PROF_MARK(0);
-        tile_t_instance_norm(tau, wave, cnt, a.scales[1][7] * (1.0f / TAIL_ACT_SCALE), a.eps, part, tot, tid, c, hh);
+        tile_t_instance_norm(tau, wave, cnt, a.scales[1][7] * (1.0f / TAIL_ACT_SCALE), a.eps, part, tot, tid, c, hh, a.status);
 #pragma unroll
         for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -1185,7 +1217,7 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
     }
     f32x16 y[4];
     head_compute(rows, a.h, a.agg[0], a.vars, nc, a.nv, a.b3[0], a.b4[0], a.w3vh[0], a.w3s[0], a.w4t[0], a.scales[0], lds, tid, lane, c, hh,
-                 y, [] {} PROF_PASS);
+                 y, [] {}, GATED || a.mode == MSMP_LAYER_LIN, tot PROF_PASS);
     PROF_MARK(2);
     // this lane's piece of the transposed tiles: nodes n0 + 32 wave + acc_row(r, hh), channels 4 c .. 4 c + 3 (tile T = channel 4 c + T)
     const size_t base = ((size_t)n0 + wave * 32 + 4 * hh) * H + 4 * c;
@@ -1207,6 +1239,12 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
             }
         }
     }
+    if (need_h) {       // range sentinel: tail_node_scaled saturates h silently (the same rows as the update heads read)
+        float mx = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(fmaxf(fmaxf(fabsf(hx[r][0]), fabsf(hx[r][1])), fmaxf(fabsf(hx[r][2]), fabsf(hx[r][3]))), mx);
+        if (mx > NODE_RANGE) status_raise(a.status, MSMP_STATUS_NODE_SATURATED);
+    }
     float unit = a.scales[0][7] * (1.0f / TAIL_ACT_SCALE);
     if (!GATED && a.mode != MSMP_LAYER_LIN) {
 #pragma unroll
@@ -1215,7 +1253,7 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
             for (int r = 0; r < 16; ++r) y[T][r] = hx[r][T] + swishf(y[T][r] * unit);
         unit = 1.0f;
     }
-    tile_t_instance_norm(y, wave, cnt, unit, a.eps, part, tot, tid, c, hh);
+    tile_t_instance_norm(y, wave, cnt, unit, a.eps, part, tot, tid, c, hh, a.status);
     PROF_MARK(3);
     if (GATED) {
 #pragma unroll
@@ -1256,7 +1294,7 @@ extern "C" int msmp_edge_mlp_f32(const float* h, const float* u, const float* po
     if (n_edges == 0) return MSMP_OK;
     const PackedLayout L = packed_layout(tw, nv);
     EdgeArgs a{h, u, pos, vars, tgt, col, nullptr, (long)n_edges, (long)n_nodes, 0, 0, tw, nv, L.nc1,
-               packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, nullptr, nullptr, msg_out, nullptr};
+               packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, nullptr, nullptr, msg_out, nullptr, status_ptr()};
     constexpr int NB = 2;
     const unsigned grid = (unsigned)((n_edges + 128 * NB - 1) / (128 * NB));
     timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
@@ -1339,7 +1377,7 @@ static int edge_aggregate(const float* h, const float* u, const float* pos, cons
     int tile_nodes = max_in_degree > 0 ? edges_per_tile / max_in_degree : edges_per_tile;
     if (tile_nodes > 256) tile_nodes = 256;      // keeps the per-tile node loop short when degrees are tiny
     EdgeArgs a{h, u, pos, vars, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, 0, tw, nv, L.nc1,
-               packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, P, Q, nullptr, agg_out};
+               packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, P, Q, nullptr, agg_out, status_ptr()};
     const unsigned grid = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
     timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
     if (P && edges_per_tile == 128 && g_split) hipLaunchKernelGGL((edge_mlp_kernel_occ2<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -1379,7 +1417,7 @@ int msmp_pair_project_aggregate(const float* h, const float* u, const float* pos
     for (int i = 0; i < 2; ++i)
         ea.head[i] = EdgeArgs{nullptr, nullptr, nullptr, nullptr, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, 0, tw, nv, L.nc1,
                               packed[i] + L.w1, packed[i] + L.w2, packed[i] + L.w2s, packed[i] + L.scales, packed[i] + L.b1,
-                              packed[i] + L.b2, pp[i], qq[i], nullptr, agg[i]};
+                              packed[i] + L.b2, pp[i], qq[i], nullptr, agg[i], status_ptr()};
     timing_begin(MSMP_K_EDGE_MLP, st);
     hipLaunchKernelGGL(edge_mlp_pair_kernel_occ2, dim3((unsigned)((n_nodes + tile_nodes - 1) / tile_nodes), 2), dim3(256), 0, st, ea);
     timing_end(MSMP_K_EDGE_MLP, st);
@@ -1428,7 +1466,7 @@ extern "C" int msmp_node_tail_f32(const float* h, const float* agg_main, const f
     const float* pg = packed_gate ? packed_gate : packed_main;
     TailArgs a{h, {agg_main, agg_gate}, vars, graph_ptr, nv, mode, eps,
                {packed_main + L.b3, pg + L.b3}, {packed_main + L.b4, pg + L.b4}, {packed_main + L.w3vh, pg + L.w3vh},
-               {packed_main + L.w3s, pg + L.w3s}, {packed_main + L.w4t, pg + L.w4t}, {packed_main + L.scales, pg + L.scales}, out};
+               {packed_main + L.w3s, pg + L.w3s}, {packed_main + L.w4t, pg + L.w4t}, {packed_main + L.scales, pg + L.scales}, out, status_ptr()};
     timing_begin(MSMP_K_NODE_UPDATE, (hipStream_t)stream);
     if (packed_gate) hipLaunchKernelGGL(node_tail_split_kernel<true>, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(node_tail_split_kernel<false>, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, a);

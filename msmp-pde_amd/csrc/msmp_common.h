@@ -102,6 +102,17 @@ __device__ __forceinline__ float sigmoidf_(float x) {
 // Row of a 32x32 MFMA accumulator register: D[row][col = lane & 31].
 __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
+// Sticky range status (msmp_last_status): `status` is the device-visible address of a host-mapped word, or nullptr.
+constexpr float NODE_RANGE = 65504.0f / 256.0f;      // |x| representable as a node row of the split path (2^8 scaling)
+__device__ __forceinline__ void status_raise(int* status, int bits) {
+    if (status) __hip_atomic_fetch_or(status, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool out_of_range(float x) { return !(fabsf(x) <= NODE_RANGE); }      // true for NaN as well
+__device__ __forceinline__ bool out_of_range(f32x4 v) {
+    return (int)out_of_range(v[0]) | (int)out_of_range(v[1]) | (int)out_of_range(v[2]) | (int)out_of_range(v[3]);
+}
+int* status_ptr();          // aux_kernels.hip: the status word as the device sees it (lazily created; nullptr if that failed)
+
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
 // reads them with 16-byte loads (instead of tw + 1 + nv scalar loads with index arithmetic per node and layer).
 __global__ __launch_bounds__(256) void pack_features_kernel(const float* __restrict__ u, const float* __restrict__ pos,
                                                             const float* __restrict__ vars, long n, int tw, int nv, int stride,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int* status) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n * stride) return;
     const long node = i / stride;
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void pack_features_kernel(const float* __restr
     else if (k == tw) v = pos[node];
     else if (k <= tw + nv) v = vars[node * nv + (k - tw - 1)];
     out[i] = v;
+    if (out_of_range(v)) status_raise(status, MSMP_STATUS_INPUT_RANGE);
 }
 
 // Feature preparation of a forward in ONE launch (experiments/models_gnn.py:1325-1352, models_gnn2D.py:104-116): from the graph's
@@ -174,6 +175,7 @@ struct PrepArgs {
     long n;
     int tw, stride;            // stride = 32 * tail chunks >= tw + 1 + (1 + n_cols)
     float *u, *pos_x, *pos_t, *vars, *feat;
+    int* status;
 };
 __device__ __forceinline__ float prep_load(const void* p, int f64, long i) {
     return f64 ? (float)reinterpret_cast<const double*>(p)[i] : reinterpret_cast<const float*>(p)[i];
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256) void prepare_nodes_kernel(PrepArgs a) {
         a.vars[node * nv + 1 + c] = v;
     }
     if (a.feat) a.feat[i] = v;
+    if (out_of_range(v)) status_raise(a.status, MSMP_STATUS_INPUT_RANGE);        // the split path saturates node rows at |x| = 255.87
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -229,6 +232,7 @@ struct TileArgs {
     const float* b1;
     const float* b2;
     float* agg;
+    int* status;           // msmp_last_status word (or nullptr)
 };
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -383,6 +387,14 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
                         }
                     }
             }
+            {       // range sentinel: node_scaled saturates silently (v_max3 drops NaN: a NaN row was flagged where it was produced)
+                float mx = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = fmaxf(fmaxf(fmaxf(fabsf(hv[i][0]), fabsf(hv[i][1])), fmaxf(fabsf(hv[i][2]), fabsf(hv[i][3]))), mx);
+#pragma unroll
+                for (int jc = 0; jc < 2; ++jc) mx = fmaxf(fmaxf(fmaxf(fabsf(tx[jc][0]), fabsf(tx[jc][1])), fmaxf(fabsf(tx[jc][2]), fabsf(tx[jc][3]))), mx);
+                if (mx > NODE_RANGE) status_raise(a.status, MSMP_STATUS_NODE_SATURATED);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = tid + 256 * i;
@@ -442,6 +454,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
             }
         };
         auto mma3 = [&](f32x16& acc, const half8& ahi, const half8& alo, const half8& whi, const half8& wlo) {
+            MSMP_MFMA_LOLO(2, acc, alo, wlo);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wlo, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, whi, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi, acc, 0, 0, 0);
@@ -555,6 +568,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         TILE_SCHED_BARRIER();
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
+            MSMP_MFMA_LOLO(2, y[T], alo[T], blo[par]);
             y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[T], bhi[par], y[T], 0, 0, 0);
             y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[T], blo[par], y[T], 0, 0, 0);
             y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[T], bhi[par], y[T], 0, 0, 0);
@@ -642,7 +656,9 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         if (node < tile_n1) {
             const int deg = r1b[k] - r0b[k];
             const float invd = 1.0f / (float)max(deg, 1);
-            *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + 4 * cq) = (sum[k] * post) * invd;
+            const f32x4 res = (sum[k] * post) * invd;
+            *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + 4 * cq) = res;
+            if (out_of_range(res)) status_raise(a.status, MSMP_STATUS_NODE_SATURATED);     // also NaN: an activation beyond fp16 upstream
         }
     }
     TPROF(9);
@@ -694,7 +710,7 @@ extern "C" int msmp_pack_node_features_f32(const float* u, const float* pos, con
     MSMP_REQUIRE(n_nodes > 0 && stride > 0, MSMP_ERR_ARG, "msmp_pack_node_features_f32: bad sizes");
     const long total = (long)n_nodes * stride;
     hipLaunchKernelGGL(pack_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, pos, vars,
-                       (long)n_nodes, tw, nv, stride, feat_out);
+                       (long)n_nodes, tw, nv, stride, feat_out, msmp_tune_get("split") ? status_ptr() : nullptr);
     return check_launch("pack_features_kernel");
 }
 
@@ -709,6 +725,7 @@ extern "C" int msmp_prepare_nodes(const void* x, int x_f64, const void* pos, int
     PrepArgs a{};
     a.x = x; a.pos = pos; a.x_f64 = x_f64; a.pos_f64 = pos_f64; a.n_cols = n_cols; a.L = L; a.tmax = tmax; a.n = (long)n_nodes; a.tw = tw;
     a.stride = stride; a.u = u_out; a.pos_x = pos_x_out; a.pos_t = pos_t_out; a.vars = vars_out; a.feat = feat_out;
+    a.status = msmp_tune_get("split") ? status_ptr() : nullptr;       // the exact-fp32 kernels have no range limit
     for (int c = 0; c < n_cols; ++c) {
         MSMP_REQUIRE(cols[c] && col_div[c] != 0.0, MSMP_ERR_ARG, "msmp_prepare_nodes: bad column %d", c);
         a.col[c] = cols[c]; a.col_f64[c] = col_f64[c]; a.col_div[c] = col_div[c];
@@ -752,7 +769,7 @@ extern "C" int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, con
     const PackedLayout L = packed_layout(tw, nv);
     MSMP_REQUIRE(!fold || L.nc1 - 8 <= 2, MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_f32: tw + 1 + nv <= 64");
     TileArgs a{h, u, pos, vars, feat, p, q, rowptr, tiles->tile_node, tiles->tile_count, msmp_tune_get("tile_arith") ? tiles->tile_halo : nullptr, tiles->edge_slot, (long)n_nodes, (long)n_edges,
-               tiles->tile_nodes, tw, nv, L.nc1, packed + L.w1s, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, agg_out};
+               tiles->tile_nodes, tw, nv, L.nc1, packed + L.w1s, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, agg_out, status_ptr()};
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_EDGE_MLP, st);
     const dim3 grid(tile_grid(tiles->n_tiles, 1));
@@ -769,6 +786,9 @@ int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* 
                                    const float* packed_b, float* agg_a, float* agg_b, msmp_stream_t stream) {
     MSMP_REQUIRE(h && u && pos && vars && rowptr && tiles && packed_a && packed_b && agg_a && agg_b, MSMP_ERR_ARG,
                  "msmp_edge_aggregate_tiled_pair: null pointer");
+    MSMP_REQUIRE(tiles->tile_node && tiles->tile_count && tiles->tile_halo && tiles->edge_slot && tiles->tile_nodes >= 1 && tiles->tile_nodes <= MSMP_TILE_NCAP &&
+                 (int64_t)tiles->n_tiles * tiles->tile_nodes >= n_nodes && (int64_t)(tiles->n_tiles - 1) * tiles->tile_nodes < n_nodes,
+                 MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_pair: tile descriptor does not cover %ld nodes", (long)n_nodes);
     const PackedLayout L = packed_layout(tw, nv);
     MSMP_REQUIRE(L.nc1 - 8 <= 2 && msmp_tune_get("split"), MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_pair: unsupported configuration");
     TileArgs2 a2;
@@ -777,7 +797,7 @@ int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* 
     for (int i = 0; i < 2; ++i)
         a2.head[i] = TileArgs{h, u, pos, vars, feat, nullptr, nullptr, rowptr, tiles->tile_node, tiles->tile_count, msmp_tune_get("tile_arith") ? tiles->tile_halo : nullptr, tiles->edge_slot, (long)n_nodes,
                               (long)n_edges, tiles->tile_nodes, tw, nv, L.nc1, packed[i] + L.w1s, packed[i] + L.w2s, packed[i] + L.scales,
-                              packed[i] + L.b1, packed[i] + L.b2, agg[i]};
+                              packed[i] + L.b1, packed[i] + L.b2, agg[i], status_ptr()};
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_EDGE_MLP, st);
     const dim3 grid(tile_grid(tiles->n_tiles, 2), 2);

@@ -20,6 +20,7 @@ dtype is float32; the result is returned in the dtype of `data.x`.
 import torch
 from torch import nn
 
+from . import _lib
 from ._lib import lib, check, ptr, current_stream, PARAM_EPOCH
 from .graph import structure_of
 from .layers import GNN_Layer, GNN_LayerLin, Swish, mp_layer, node_features
@@ -313,6 +314,7 @@ class _SolverBase(nn.Module):
         return r
 
     def forward(self, data):
+        _lib.status_check()       # range sentinel of the fp16-split path: one host read, warns once per new flag (no device sync)
         u_in = data.x
         pos = data.pos
         gs = structure_of(data)

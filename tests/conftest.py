@@ -90,3 +90,22 @@ def _guard_bands(request):
         bad = cnt if bad is None else bad + cnt
     n_bad = int(bad.item()) if bad is not None else 0
     assert n_bad == 0, f'{n_bad} guard-band elements around kernel outputs / workspaces were overwritten (out-of-bounds stores)'
+
+
+@pytest.fixture(autouse=True)
+def _range_status_stays_clear(request):
+    """Every GPU test must leave the sticky range status of the fp16-split path (msmp_last_status) at 0: no test input may
+    saturate or overflow silently.  Tests that trip it on purpose clear it themselves (last_status(reset=True))."""
+    if 'gpu' not in request.keywords:
+        yield
+        return
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    import msmp_pde_amd as mp
+    mp.last_status(reset=True)
+    yield
+    torch.cuda.synchronize()
+    flags = mp.last_status(reset=True)
+    assert flags == 0, f'range status {flags} left behind: a kernel saturated a node row or met a non-finite value'

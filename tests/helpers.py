@@ -55,12 +55,12 @@ def deep_state_dict(d, shapes=None):
 DEEP_CASES = [('MP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'E2'), ('MP_PDE_SolverGated', 'WE3'),
               ('MP_PDE_Solver2DGated', 'MSWG3'), ('MP_PDE_Solver2DGated', 'RPU')]
 
-_PARITY_LOG = os.environ.get('MSMP_PARITY_LOG', os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out', 'parity_r02.json'))
+_PARITY_LOG = os.environ.get('MSMP_PARITY_LOG', os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out', 'parity_r03.json'))
 
 
 def record_parity(test, case, **numbers):
     """Append one measured parity record (max / rms error, float32 floor, bar) to the JSON log the GPU run leaves under
-    gpurun_out/ (copied to profiles/parity_r02.json): the numbers behind every tolerance are on record, not only pass/fail."""
+    gpurun_out/ (copied to profiles/parity_r03.json): the numbers behind every tolerance are on record, not only pass/fail."""
     import json
     path = os.path.abspath(_PARITY_LOG)
     try:
@@ -83,9 +83,8 @@ def err_stats(out, ref):
 TOL = 1e-5      # BASELINE.json north_star: "fp32 node output within 1e-5 of the CPU reference"
 
 
-FLOOR_FACTOR = 5.0       # on the max error; 3 on the rms error.  Measured worst cases of round 2 (profiles/parity_r02.json): max 4.0 x, rms 3.0 x
-                         # (the torch-GPU floor itself moves by +-10 % from run to run: index_add_ atomics)
-FLOOR_FACTOR_RMS = 3.0
+FLOOR_FACTOR = 2.0       # on the max error and on the rms error.  Measured worst case of round 3 among the cases that miss the plain 1e-5
+FLOOR_FACTOR_RMS = 2.0   # (profiles/parity_r03.json): 1.49 x max / 1.43 x rms (an LSTM ablation); the six SURVEY section-8 classes <= 1.18 x / 0.87 x
 
 
 def fp32_floors(kind, sd, g, pde, tw, eqv, layers):
@@ -107,10 +106,10 @@ def assert_parity(test, case, out, ref, floor_out=None, tol=TOL):
     configurations ANY float32 evaluation is farther than 1e-5 from float64.  That is measured, not assumed: `floor_out` is
     the float64-checked oracle evaluated in float32 (an array, or a dict of several such evaluations: fp32_floors; the floor is
     then the largest of them, i.e. the spread of float32 results).  Where float32 arithmetic itself cannot deliver 1e-5 the HIP
-    path is held to the float32 floor instead: max error <= max(1e-5, FLOOR_FACTOR (5) x floor_max) AND rms error <=
-    max(1e-5, FLOOR_FACTOR_RMS (3) x floor_rms).  Why not 1 x: both floors are BLAS evaluations (blocked / pairwise
-    accumulation), about as accurate as float32 gets; the kernels here carry every GEMM operand as an fp16 pair (22-23
-    significant bits instead of 24) and accumulate K sequentially in fp32 ("Numerics")."""
+    path is held to the float32 floor instead: max error <= max(1e-5, 2 x floor_max) AND rms error <= max(1e-5, 2 x floor_rms).
+    Round 3 measured the gated classes BELOW the floor (0.8-0.9 x rms: update_net_2 runs on the variation of its input over the
+    graph); the factor 2 is what the max norm of a heavy-tailed error needs between two float32 evaluations
+    of the same formulas (numpy vs torch-GPU floors differ by up to 1.5 x between themselves)."""
     err, rms = err_stats(out, ref)
     floor = floor_rms = None
     floors = {}
@@ -180,3 +179,39 @@ def synthetic_case(mp, exp, bsz, seed, device='cuda', step=50):
         return g
     out.graph_np = graph_np
     return out
+
+
+def layer_error_profile(mp, kind, exp, bsz=8, seed=11, layers=6, tw=25):
+    """Per-layer error of the hidden state against the float64 oracle: the HIP path (its own chain of layers, and every layer
+    applied "fresh" to the oracle's exact input) next to a float32 evaluation of the oracle.  (max, rms) pairs.
+    Used by test_layer_error_growth and scripts/diag_lolo.py."""
+    import torch
+    from msmp_pde_amd.graph import structure_of
+    from oracle import msmp_oracle as O
+    torch.manual_seed(3)
+    case = synthetic_case(mp, exp, bsz=bsz, seed=seed)
+    model = getattr(mp, kind)(case.pde, time_window=tw, eq_variables=case.eqv, hidden_layer=layers).cuda().eval()
+    data = case.graph.to('cuda')
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    g = case.graph_np()
+    r64 = O.solver_forward(kind, sd, g, case.pde, tw, case.eqv, layers, parts=True)
+    r32 = O.solver_forward(kind, sd, g, case.pde, tw, case.eqv, layers, dtype=np.float32, parts=True)
+    rec = {'kind': kind, 'exp': exp, 'layers': []}
+    with torch.no_grad():
+        u, pos_x, pos_t, var, feat = model._prepare(data, True)
+        gs = structure_of(data)
+        feat = feat if gs.tiles() is not None else None
+        dt = torch.cumsum(torch.ones(tw, device='cuda') * case.pde.dt, 0)
+        h = model._encode(u, pos_x, pos_t, var, dt)
+        rec['encoder'] = {'hip': err_stats(h.double().cpu().numpy(), r64.h_enc), 'f32': err_stats(r32.h_enc, r64.h_enc)}
+        for i in range(layers):
+            gate = model.gnn_layers_gate[i] if model.GATED else None
+            h = mp.mp_layer(h, u, pos_x, var, gs, model.gnn_layers[i], gate, feat=feat)
+            hin = torch.tensor(r64.hs[i - 1] if i else r64.h_enc).float().cuda()
+            hf = mp.mp_layer(hin, u, pos_x, var, gs, model.gnn_layers[i], gate, feat=feat)
+            rec['layers'].append({'hip': err_stats(h.double().cpu().numpy(), r64.hs[i]), 'f32': err_stats(r32.hs[i], r64.hs[i]),
+                                  'hip_fresh': err_stats(hf.double().cpu().numpy(), r64.hs[i])})
+        out = model(data)
+    rec['out'] = {'hip': err_stats(out.double().cpu().numpy(), r64.out), 'f32': err_stats(r32.out, r64.out),
+                  'ref_max': float(np.abs(r64.out).max())}
+    return rec

@@ -41,8 +41,8 @@ def subgraph(graph, ids, nx):
 
 @pytest.mark.parametrize('kind,exp,layers', [('MP_PDE_SolverLEMLinGated', 'E2', 6), ('MP_PDE_Solver', 'E2', 6),
                                              ('MP_PDE_SolverLEMLinGated', 'WE3', 6),
-                                             ('MP_PDE_SolverGated', 'WE3', 2), ('MP_PDE_Solver2DLEMLinGated', 'RPU', 2),
-                                             ('MP_PDE_Solver2DGated', 'MSWG3', 2)])
+                                             ('MP_PDE_SolverGated', 'WE3', 2), ('MP_PDE_Solver2DLEMLinGated', 'RPU', 6),
+                                             ('MP_PDE_Solver2DLEMLinGated', 'MSWG3', 6), ('MP_PDE_Solver2DGated', 'MSWG3', 2)])
 def test_full_size_batch_properties(mp, kind, exp, layers):
     from msmp_pde_amd.synthetic import make_case
     torch.manual_seed(11)

@@ -131,6 +131,7 @@ def test_full_depth_vs_reference_golden(mp, kind, exp):
                                       ('MP_PDE_SolverLEMLinGated', 'E2'), ('MP_PDE_SolverGated', 'WE3'),
                                       ('MP_PDE_SolverLEMLinGated', 'WE3'),
                                       ('MP_PDE_Solver2DLEMLinGated', 'RPU'), ('MP_PDE_Solver2DGated', 'MSWG3'),
+                                      ('MP_PDE_Solver2DLEMLinGated', 'MSWG3'),      # BASELINE.json configs[4] as named, at the default depth
                                       ('MP_PDE_SolverLEMLin', 'E2'), ('MP_PDE_Solver2DLEMLin', 'MSWG3'),
                                       ('MP_PDE_Solver2DLEMLinG2', 'RPU'), ('MSSMP_PDE_Solver', 'E2'),
                                       ('MP_PDE_SolverLSTMLinGated', 'E2'), ('MP_PDE_SolverLSTMLin', 'WE3'),
@@ -152,6 +153,31 @@ def test_full_depth_vs_oracle(mp, kind, exp):
     ref = O.solver_forward(kind, sd, g, case.pde, TW, case.eqv, 6)
     floor = fp32_floors(kind, sd, g, case.pde, TW, case.eqv, 6)
     assert_parity('full_depth_vs_oracle', f'{kind}/{exp}', out.double().cpu().numpy(), ref, floor)     # bar: helpers.assert_parity
+
+
+@pytest.mark.parametrize('kind,exp', [('MP_PDE_SolverLEMLinGated', 'E2'), ('MP_PDE_SolverLEMLinGated', 'WE3'),
+                                      ('MP_PDE_Solver2DLEMLinGated', 'MSWG3')])
+def test_layer_error_growth(mp, kind, exp):
+    """Conditioning-independent form of the full-depth bar: layer by layer, the error of the HIP hidden
+    state against the float64 oracle may not exceed 1.5 x the error a float32 evaluation of the oracle has at the same layer,
+    and may not GROW faster from one layer to the next than 1.5 x the float32 evaluation's growth (rms over all nodes and
+    channels; both chains see the same ill-conditioned InstanceNorm stack, so the ratio does not depend on the weights).  The
+    error a layer ADDS on exact input ("fresh") must stay below 5e-7 rms: before round 3 layer pairs 0 and 1 added 8e-7
+    (update_net_2's 24 accumulator roundings relative to |y| instead of its spread, scripts/diag_quant.py)."""
+    from helpers import layer_error_profile, record_parity
+    r = layer_error_profile(mp, kind, exp)
+    hip = [r['encoder']['hip'][1]] + [l['hip'][1] for l in r['layers']]
+    f32 = [r['encoder']['f32'][1]] + [l['f32'][1] for l in r['layers']]
+    fresh = [l['hip_fresh'][1] for l in r['layers']]
+    record_parity('layer_error_growth', f'{kind}/{exp}', hip_rms=hip, f32_rms=f32, fresh_rms=fresh,
+                  out_hip=r['out']['hip'], out_f32=r['out']['f32'])
+    print(f'{kind}/{exp}: rms hip/f32 per layer ' + ' '.join(f'{a / b:.2f}' for a, b in zip(hip[1:], f32[1:]))
+          + ' | fresh ' + ' '.join(f'{x:.1e}' for x in fresh))
+    for i in range(1, len(hip)):
+        assert hip[i] <= 1.5 * f32[i], (i, hip[i], f32[i])
+        if i > 1:
+            assert hip[i] / hip[i - 1] <= 1.5 * f32[i] / f32[i - 1], (i, hip[i] / hip[i - 1], f32[i] / f32[i - 1])
+    assert max(fresh) <= 5e-7, fresh
 
 
 def test_graph_sharding_is_exact(mp):
@@ -445,6 +471,54 @@ def test_input_range_guard_and_exact_fp32_fallback(mp):
     err = np.abs(out.double().cpu().numpy() - ref).max()
     print(f'offset input (|u| ~ 1000) on the exact-fp32 kernels: max|hip - oracle| = {err:.3e} on outputs of magnitude {np.abs(ref).max():.4g}')
     assert np.isfinite(out.cpu().numpy()).all() and err < 2e-3 * np.abs(ref).max()
+    torch.cuda.synchronize()
+    assert mp.last_status(reset=True) == mp.MSMP_STATUS_INPUT_RANGE      # raised by validate_inputs' prepare launch on the split path; the fp32 run added nothing
+
+
+@pytest.mark.gpu
+def test_range_sentinel_in_plain_forward(mp):
+    """The fp16-split path may not leave its range silently (ADVICE r02 / VERDICT r02 item 1f).  (1) an input of |u| ~ 1000 through
+    plain forward(): the status word carries INPUT_RANGE (prepare kernel) and NODE_SATURATED (tile staging) once the work has
+    completed, and the NEXT forward warns (one host read, no sync inside forward).  (2) hidden activations beyond fp16 (|Swish| >
+    1023, made with a huge message_net_1 bias): NODE_SATURATED (the aggregate is NaN / out of range) or NONFINITE (the norm's
+    statistics).  (3) in-range data leaves the word at 0 (also asserted after every GPU test by conftest)."""
+    import warnings
+    from msmp_pde_amd.synthetic import make_case
+    torch.manual_seed(3)
+    c = make_case('E2', 3, seed=9, device='cuda', dtype=torch.float64)
+    steps = [50] * 3
+    data, labels = c.creator.create_data(c.u_super, steps)
+    graph = c.creator.create_graph(data, labels, c.x, c.variables, steps)
+    model = mp.MP_PDE_SolverLEMLinGated(c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=2).cuda().eval()
+    with torch.no_grad():
+        model(graph)
+    torch.cuda.synchronize()
+    assert mp.last_status() == 0                                     # (3)
+    x0 = graph.x
+    graph.x = x0 + 1000.0
+    with torch.no_grad():
+        model(graph)
+    torch.cuda.synchronize()
+    flags = mp.last_status()
+    assert flags & mp.MSMP_STATUS_INPUT_RANGE and flags & mp.MSMP_STATUS_NODE_SATURATED, flags           # (1)
+    graph.x = x0
+    with pytest.warns(mp.MsmpRangeWarning, match='split'):
+        with torch.no_grad():
+            model(graph)
+    with warnings.catch_warnings():                                  # ... once: the same flags do not warn again
+        warnings.simplefilter('error', mp.MsmpRangeWarning)
+        with torch.no_grad():
+            model(graph)
+    torch.cuda.synchronize()
+    assert mp.last_status(reset=True) == flags                       # sticky until reset; in-range work added nothing
+    with torch.no_grad():                                            # (2)
+        model.gnn_layers[0].message_net_1[0].bias.fill_(5000.0)
+        mp.invalidate_packed_weights()
+        out = model(graph)
+    torch.cuda.synchronize()
+    flags = mp.last_status(reset=True)
+    assert flags & (mp.MSMP_STATUS_NODE_SATURATED | mp.MSMP_STATUS_NONFINITE), (flags, bool(torch.isfinite(out).all()))
+    assert not flags & mp.MSMP_STATUS_INPUT_RANGE
 
 
 @pytest.mark.gpu
