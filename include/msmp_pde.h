@@ -176,27 +176,32 @@ int msmp_edge_aggregate_projected_f32(const float* p, const float* q, const int3
 
 /* Node tiles for the LDS-staged message kernel (north_star: "LDS staging of node tiles for edge gather"; the gathers it
  * replaces are PyG propagate's x_i = x[edge_index[1]], x_j = x[edge_index[0]], experiments/models_gnn.py:65,128).
- * A tile = `tile_nodes` consecutive TARGET nodes with all their in-edges (at most MSMP_TILE_EDGES) plus every node those
- * edges read as a source: at most MSMP_TILE_NCAP distinct nodes, listed per tile with the targets first (slot k < tile size
- * is node tile * tile_nodes + k), so the kernel loads each node row of a tile ONCE (coalesced, 512-byte rows) into LDS and
- * every edge reads its two operands from there through the per-edge slot pair.  Works for any graph whose tiles fit (banded
- * 1-D radius / knn graphs, periodic wrap-around included: the list is by node id, not by window); msmp_build_tiles reports
- * the largest list / edge count it met so the caller can pick a smaller tile_nodes or fall back to the gather kernels. */
+ * A tile = four WAVE GROUPS of `group_nodes` consecutive TARGET nodes each (tile_nodes = 4 group_nodes) with all their in-edges
+ * (at most 32 per group: one lane per edge, a target's edges never straddle two waves, so the per-target mean is one more MFMA
+ * on the wave's message tile) plus every node those edges read as a source: at most MSMP_TILE_NCAP distinct nodes, listed per
+ * tile with the targets first (slot k < tile size is node tile * tile_nodes + k), so the kernel loads each node row of a tile
+ * ONCE (coalesced, 512-byte rows) into LDS and every edge reads its two operands from there through the per-edge slot pair.
+ * Works for any graph whose tiles fit (banded 1-D radius / knn graphs, periodic wrap-around included: the list is by node id, not
+ * by window); msmp_build_tiles reports the largest list / group edge count it met so the caller can pick a smaller group_nodes
+ * or fall back to the gather kernels (always for in-degrees above 32). */
 #define MSMP_TILE_NCAP  32       /* distinct nodes of a tile: one 32-row MFMA block */
-#define MSMP_TILE_EDGES 128      /* in-edges of a tile: one 32-edge block per wave */
+#define MSMP_TILE_EDGES 128      /* edge lanes of a tile: one 32-lane group per wave */
 typedef struct {
-    int32_t tile_nodes;          /* target nodes per tile */
+    int32_t tile_nodes;          /* target nodes per tile = 4 * group_nodes */
+    int32_t group_nodes;         /* target nodes per wave group */
     int32_t n_tiles;             /* ceil(n_nodes / tile_nodes) */
     const int32_t* tile_node;    /* [n_tiles][MSMP_TILE_NCAP] node ids (unused slots repeat the tile's first node) */
     const int32_t* tile_count;   /* [n_tiles] number of valid slots */
     const int32_t* tile_halo;    /* [n_tiles][4]: (lo start, lo count, hi start, hi count) when the tile's sources outside it are one
                                   * run of consecutive nodes below and one above (slots then follow node order and the kernel needs
                                   * no list lookup); lo count = -1 otherwise */
-    const int32_t* edge_slot;    /* [n_tiles][MSMP_TILE_EDGES]: k-th in-edge of the tile (CSR order): target slot | source slot << 8; 0 past the tile's edges */
+    const int32_t* edge_slot;    /* [n_tiles][MSMP_TILE_EDGES]: lane 32 g + k = k-th in-edge (CSR order) of wave group g: target slot | source slot << 8;
+                                  * 0 at lanes without an edge */
 } msmp_tiles_t;
-/* stats_out (device, 2 x int32): largest node list, largest edge count over the tiles (lists longer than MSMP_TILE_NCAP are
- * truncated in the output: the structure is then not usable with this tile_nodes). */
-int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int64_t n_edges, int tile_nodes,
+/* stats_out (device, 2 x int32): largest node list, largest edge count of a wave group over the tiles (lists longer than
+ * MSMP_TILE_NCAP are truncated in the output, groups of more than 32 edges cut: the structure is then not usable with this
+ * group_nodes). */
+int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int64_t n_edges, int group_nodes,
                      int32_t* tile_node_out, int32_t* tile_count_out, int32_t* tile_halo_out, int32_t* edge_slot_out,
                      int32_t* stats_out, msmp_stream_t stream);
 /* L1 + L2 on node tiles: same result as msmp_edge_aggregate_projected_f32 (p, q given: the tile's P / Q rows are staged in

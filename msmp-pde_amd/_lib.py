@@ -9,12 +9,13 @@ LIB_PATH = os.environ.get('MSMP_LIB_PATH') or os.path.join(PKG, 'libmsmp_pde.so'
 
 class MsmpTiles(ctypes.Structure):
     """msmp_tiles_t (include/msmp_pde.h): node tiles of the LDS-staged message kernel."""
-    _fields_ = [('tile_nodes', ctypes.c_int32), ('n_tiles', ctypes.c_int32), ('tile_node', c_void_p), ('tile_count', c_void_p),
+    _fields_ = [('tile_nodes', ctypes.c_int32), ('group_nodes', ctypes.c_int32), ('n_tiles', ctypes.c_int32), ('tile_node', c_void_p), ('tile_count', c_void_p),
                 ('tile_halo', c_void_p), ('edge_slot', c_void_p)]
 
 
 MSMP_TILE_NCAP = 32
 MSMP_TILE_EDGES = 128
+MSMP_TILE_GROUP_EDGES = 32      # edge lanes of one wave group of a tile
 MSMP_LAYER_RESIDUAL_SWISH = 0
 MSMP_LAYER_LIN = 1
 MSMP_ERR_UNSUPPORTED = -2

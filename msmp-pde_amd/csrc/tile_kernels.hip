@@ -55,24 +55,29 @@ __device__ __forceinline__ float node_scaled(float x) { return __builtin_amdgcn_
 // Tile metadata: one 128-thread workgroup per tile.
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, int n_nodes,
-                                                          int tile_nodes, int* __restrict__ tile_node, int* __restrict__ tile_count,
-                                                          int* __restrict__ tile_halo, int* __restrict__ edge_slot,
-                                                          int* __restrict__ stats) {
-    __shared__ int s_col[TILE_EDGES];
+                                                          int tile_nodes, int group_nodes, int* __restrict__ tile_node,
+                                                          int* __restrict__ tile_count, int* __restrict__ tile_halo,
+                                                          int* __restrict__ edge_slot, int* __restrict__ stats) {
+    __shared__ int s_col[TILE_EDGES];       // source of the edge at lane k, -1: no edge at this lane
     __shared__ int s_first[TILE_EDGES];     // 1: first occurrence of an out-of-range source
     __shared__ int s_slot[TILE_EDGES];
     __shared__ int s_halo[5];               // lo start, lo count, hi start, hi count, ranged
     const int t = blockIdx.x, k = threadIdx.x;
     const int n0 = t * tile_nodes, n1 = min(n0 + tile_nodes, n_nodes);
-    const int e0 = rowptr[n0], e1 = rowptr[n1];
-    const int ne = e1 - e0, nt = n1 - n0;
-    const int nek = min(ne, TILE_EDGES);
+    const int nt = n1 - n0;
+    // Wave groups: wave g of the message kernel owns the targets [gf, gl) and ALL their in-edges, at lanes 32 g ...; a target's
+    // edges never straddle two waves, so the per-target sum is wave-local (one more MFMA on the message tile, no LDS staging).
+    const int g = k >> 5, kk = k & 31;
+    const int gf = min(n0 + g * group_nodes, n1), gl = min(gf + group_nodes, n1);
+    const int ge0 = rowptr[gf], ge1 = rowptr[gl];
+    const bool valid = kk < ge1 - ge0 && kk < 32;
+    const int e = ge0 + kk;
     int j = -1;
-    if (k < nek) j = col[e0 + k];
+    if (valid) j = col[e];
     s_col[k] = j;
     __syncthreads();
     int first = 0, owner = k;
-    if (k < nek && (j < n0 || j >= n1)) {
+    if (valid && (j < n0 || j >= n1)) {
         first = 1;
         for (int i = 0; i < k; ++i)
             if (s_col[i] == j) { first = 0; owner = i; break; }
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
     // the node list first and the rows second (two dependent global reads at the head of every tile).
     if (k == 0) {
         int lo_min = 0x7fffffff, lo_max = -1, lo_cnt = 0, hi_min = 0x7fffffff, hi_max = -1, hi_cnt = 0;
-        for (int i = 0; i < nek; ++i)
+        for (int i = 0; i < TILE_EDGES; ++i)
             if (s_first[i]) {
                 const int v = s_col[i];
                 if (v < n0) { lo_min = min(lo_min, v); lo_max = max(lo_max, v); ++lo_cnt; }
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
     __syncthreads();
     const bool ranged = s_halo[4] != 0;
     int slot = 0;
-    if (k < nek) {
+    if (valid) {
         if (j >= n0 && j < n1) slot = j - n0;
         else if (ranged) slot = j < n0 ? nt + (j - s_halo[0]) : nt + s_halo[1] + (j - s_halo[2]);
         else if (first) {
@@ -108,21 +113,22 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
     }
     s_slot[k] = slot;
     __syncthreads();
-    if (k < nek && !(j >= n0 && j < n1) && !first && !ranged) slot = s_slot[owner];
+    if (valid && !(j >= n0 && j < n1) && !first && !ranged) slot = s_slot[owner];
     // outputs
-    if (k < nek) {
-        // target slot of edge e0 + k: the CSR row it lies in (rows of a tile are short: linear search over <= tile_nodes rows)
-        int ts = 0;
-        while (ts + 1 < nt && rowptr[n0 + ts + 1] <= e0 + k) ++ts;
+    if (valid) {
+        // target slot of edge e: the CSR row it lies in (rows of a group are short: linear search over <= group_nodes rows)
+        int ts = gf - n0;
+        while (ts + 1 < gl - n0 && rowptr[n0 + ts + 1] <= e) ++ts;
         edge_slot[(size_t)t * TILE_EDGES + k] = ts | (min(slot, 255) << 8);
         if (first && slot < TILE_NCAP) tile_node[(size_t)t * TILE_NCAP + slot] = j;
-    } else if (k < TILE_EDGES)
-        edge_slot[(size_t)t * TILE_EDGES + k] = 0;           // lanes past the tile's edges read a valid slot pair; their messages are never summed
+    } else
+        edge_slot[(size_t)t * TILE_EDGES + k] = 0;           // lanes without an edge read a valid slot pair; their messages are never summed
     if (k < TILE_NCAP && k < nt) tile_node[(size_t)t * TILE_NCAP + k] = n0 + k;
     __syncthreads();
+    int total = nt;
+    if (k == 0 || k < TILE_NCAP)
+        for (int i = 0; i < TILE_EDGES; ++i) total += s_first[i];
     if (k == 0) {
-        int total = nt;
-        for (int i = 0; i < nek; ++i) total += s_first[i];
         tile_count[t] = min(total, TILE_NCAP);
         const bool use = ranged && total <= TILE_NCAP;
         tile_halo[4 * t + 0] = use ? s_halo[0] : 0;
@@ -130,15 +136,11 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
         tile_halo[4 * t + 2] = use ? s_halo[2] : 0;
         tile_halo[4 * t + 3] = use ? s_halo[3] : 0;
         atomicMax(&stats[0], total);
-        atomicMax(&stats[1], ne);
     }
+    if (kk == 0) atomicMax(&stats[1], ge1 - ge0);             // edges of one wave group: must fit 32 lanes
     // unused slots repeat the first node (valid addresses for unconditional loads): slots >= total were never written above
     __syncthreads();
-    if (k < TILE_NCAP) {
-        int total = nt;
-        for (int i = 0; i < nek; ++i) total += s_first[i];
-        if (k >= total) tile_node[(size_t)t * TILE_NCAP + k] = n0;
-    }
+    if (k < TILE_NCAP && k >= total) tile_node[(size_t)t * TILE_NCAP + k] = n0;
 }
 
 // Per-node rows of the columns of message_net_1 that are not hidden state: [u (tw) | pos | vars (nv) | 0 ...], padded to whole
@@ -224,7 +226,7 @@ struct TileArgs {
     const int* tile_halo;
     const int* edge_slot;
     long n_nodes, n_edges;
-    int tile_nodes;
+    int tile_nodes, group_nodes;      // group_nodes = tile_nodes / 4: targets of one wave
     int tw, nv, nc1;
     const float* w1s;      // FOLD: nc1 split chunks, natural k order, fragment row (T, lane) = W1 row 32 T + lane
     const float* w2s;      // 4 split chunks (acc order)
@@ -245,9 +247,10 @@ struct TileArgs {
 //   * the mean epilogue stages the messages in two rounds of 64 edges (33 KB), partial sums carried in registers in CSR order.
 constexpr int WHALF_FLOATS = SPLIT_CHUNK_FLOATS / 2;                            // 8 KB: one K = 16 step of a split chunk
 constexpr int WBUF_FLOATS = 2 * WHALF_FLOATS;
-constexpr int TILE_LDS_FLOATS = WBUF_FLOATS + 2 * TILE_NCAP * PQLD;      // 12 544 floats = 50 176 B
-static_assert(8 * 32 * BROW_T * 2 <= TILE_LDS_FLOATS * 4, "fragment tile of the folded projections must fit");
-static_assert((TILE_EDGES / 2) * (H + 4) <= TILE_LDS_FLOATS, "one epilogue round must fit");
+constexpr int TILE_MAIN_FLOATS = WBUF_FLOATS + 2 * TILE_NCAP * PQLD;      // 12 544 floats = 50 176 B
+constexpr int TILE_LUT_FLOATS = 32;                                       // 16 entries x 8 B: nibble -> four fp16 0 / 1 (the mean's selection matrix)
+constexpr int TILE_LDS_FLOATS = TILE_MAIN_FLOATS + TILE_LUT_FLOATS;       // 50 304 B: three workgroups per CU
+static_assert(8 * 32 * BROW_T * 2 <= TILE_MAIN_FLOATS * 4, "fragment tile of the folded projections must fit");
 
 struct WHalf {
     f32x4 r[2];
@@ -275,7 +278,6 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
     (void)n_tiles;
     const int tile_n0 = tile * a.tile_nodes;
     const int tile_n1 = (int)min((long)tile_n0 + a.tile_nodes, a.n_nodes);
-    const int tile_e0 = a.rowptr[tile_n0];
     const int* tnode = a.tile_node + (size_t)tile * TILE_NCAP;
     int h_lo = 0, h_nlo = -1, h_hi = 0, h_nhi = 0;
     if (a.tile_halo) { h_lo = a.tile_halo[4 * tile]; h_nlo = a.tile_halo[4 * tile + 1]; h_hi = a.tile_halo[4 * tile + 2]; h_nhi = a.tile_halo[4 * tile + 3]; }
@@ -286,9 +288,26 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         return r < 0 ? tile_n0 + slot : (r < h_nlo ? h_lo + r : (r < h_nlo + h_nhi ? h_hi + (r - h_nlo) : tile_n0));
     };
 
-    // slot pair of this lane's edge: stored per TILE ([tile][128], zero past the tile's edges), so the load depends on nothing but
+    // slot pair of this lane's edge: stored per TILE ([tile][128], zero at lanes without an edge), so the load depends on nothing but
     // the workgroup's index (not on rowptr: one memory round trip less on the tile's critical path)
     const int sl = a.edge_slot[(size_t)tile * TILE_EDGES + wave * 32 + c];
+    // this wave's targets [gf, gl) and, for lane c < gl - gf, the lanes [er0, er0 + edeg) of this wave that hold target gf + c's in-edges
+    // (consumed by the mean at the very end: requested here, off the critical path)
+    const int gf = min(tile_n0 + wave * a.group_nodes, tile_n1), gl = min(gf + a.group_nodes, tile_n1);
+    int er0 = 0, edeg = 0;
+    {
+        const int ebase = a.rowptr[gf];
+        if (c < gl - gf) {
+            er0 = a.rowptr[gf + c] - ebase;
+            edeg = a.rowptr[gf + c + 1] - ebase - er0;
+        }
+    }
+    // nibble -> four fp16 values 0 / 1: the building block of the mean's selection matrix (read after many barriers)
+    if (tid < 16) {
+        unsigned* lut = reinterpret_cast<unsigned*>(lds + TILE_MAIN_FLOATS);
+        lut[2 * tid] = ((tid & 1) ? 0x3C00u : 0u) | ((tid & 2) ? 0x3C000000u : 0u);
+        lut[2 * tid + 1] = ((tid & 4) ? 0x3C00u : 0u) | ((tid & 8) ? 0x3C000000u : 0u);
+    }
     const float* prow = pl + (sl & 255) * PQLD + 4 * hh;
     const float* qrow = ql + ((sl >> 8) & 255) * PQLD + 4 * hh;
 
@@ -495,30 +514,20 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         TPROF(2);
     }
 
-    const int nslot = tid >> 5, cq = tid & 31;
-    int r0b[4], r1b[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int node = tile_n0 + nslot + 8 * k;
-        const int nodec = node < tile_n1 ? node : tile_n1 - 1;
-        const int v0 = a.rowptr[nodec], v1 = a.rowptr[nodec + 1];
-        r0b[k] = v0 - tile_e0;
-        r1b[k] = node < tile_n1 ? v1 - tile_e0 : v0 - tile_e0;
-    }
-
     // ---- message_net_2 on Swish(P_i + Q_j): eight K = 16 steps u = 2 t + s; the matrix work of step u (12 MFMAs = 4 groups of 3)
     // is interleaved with the activation of the same K step of the NEXT chunk (4 slices of two values), as in edge_tile_body.
+    // The GEMM is computed TRANSPOSED (the activation fragments are the A operand, the W2 fragments the B operand: both have the
+    // same lane / k structure): y[T][r] = message_net_2 of edge acc_row(r, hh) of this wave, channel 32 T + c.  Registers 8 s .. 8 s + 7
+    // of a tile are then exactly the B fragment of K step s of one more MFMA over the wave's 32 edges: the per-target sum.
     f32x16 y[4];
     {
         const float s2 = a.scales[1] * ACT_SCALE;
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
+        for (int T = 0; T < 4; ++T) {
+            const float bv = a.b2[32 * T + c] * s2;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b2 + 32 * T + 8 * q + 4 * hh);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) y[T][4 * q + m] = bv[m] * s2;
-            }
+            for (int r = 0; r < 16; ++r) y[T][r] = bv;
+        }
     }
     f32x4 pq[4];                 // P (0, 1) and Q (2, 3) pieces of the K step being activated: channels 32 t + 16 s + 8 j + 4 hh .. + 3
     auto gather_step = [&](int t, int s) {
@@ -568,10 +577,10 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         TILE_SCHED_BARRIER();
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
-            MSMP_MFMA_LOLO(2, y[T], alo[T], blo[par]);
-            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[T], bhi[par], y[T], 0, 0, 0);
-            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[T], blo[par], y[T], 0, 0, 0);
-            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[T], bhi[par], y[T], 0, 0, 0);
+            MSMP_MFMA_LOLO(2, y[T], blo[par], alo[T]);
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[par], alo[T], y[T], 0, 0, 0);
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blo[par], ahi[T], y[T], 0, 0, 0);
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[par], ahi[T], y[T], 0, 0, 0);
             TILE_SCHED_BARRIER();
             if (u < 7) {
                 act_slice(T);
@@ -587,79 +596,98 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         TPROF(5);
     }
 
-    // ---- mean over the in-edges of each target, CSR order, in two rounds of 64 staged edges ----------------------------------------
-    constexpr int LDR = H + 4;
-    const float inv2 = a.scales[5] * (1.0f / ACT_SCALE);
+    // ---- mean over the in-edges of each target: one more MFMA per channel tile, wave-local (no LDS staging, no barrier) ----------------
+    // m64 = 64 Swish(y) in place.  The accumulators hold yy = 2^s 64 y; with kinv = 2^s:  m64 = yy / (kinv (1 + e^-y)).
+    {
+        const float kinv = a.scales[1];
+        const float inv2 = a.scales[5] * (1.0f / ACT_SCALE);
 #if MSMP_PRECISE_ACT
-    const float post = 1.0f;
+        (void)kinv;
 #else
-    const float cexp = -1.44269504088896340736f * inv2;
-    const float post = inv2;
+        const float cexp = -1.44269504088896340736f * inv2;
 #endif
-    // Swish of the accumulators IN PLACE, all four waves at once (with the activation inside the rounds, two waves computed it
-    // while the other two waited at the round's barrier: the vector work of this phase ran twice in series)
 #pragma unroll
-    for (int T = 0; T < 4; ++T)
+        for (int T = 0; T < 4; ++T)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
+            for (int r = 0; r < 16; r += 2) {
 #if MSMP_PRECISE_ACT
-            y[T][r] = swishf(y[T][r] * inv2);
-            y[T][r + 1] = swishf(y[T][r + 1] * inv2);
+                y[T][r] = ACT_SCALE * swishf(y[T][r] * inv2);
+                y[T][r + 1] = ACT_SCALE * swishf(y[T][r + 1] * inv2);
 #else
-            const f32x2 yy = {y[T][r], y[T][r + 1]};
-            const f32x2 t = yy * f32x2{cexp, cexp};
-            const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
-            const f32x2 z = yy * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-            y[T][r] = z[0];
-            y[T][r + 1] = z[1];
+                const f32x2 yy = {y[T][r], y[T][r + 1]};
+                const f32x2 t = yy * f32x2{cexp, cexp};
+                const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                const f32x2 d = e * f32x2{kinv, kinv} + f32x2{kinv, kinv};
+                const f32x2 z = yy * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                y[T][r] = z[0];
+                y[T][r + 1] = z[1];
 #endif
+            }
+    }
+    TPROF(6);
+    // Selection matrix S[target row n][edge k] = 1 iff lane k of this wave holds an in-edge of target gf + n: the A operand, built
+    // from the lane's edge range as a bit mask; K index j of step s is edge 16 s + 8 (j >> 2) + 4 hh + (j & 3) (the accumulator's row order).
+    half8 sf[2];
+    {
+        const unsigned mask = edeg >= 32 ? 0xffffffffu : ((1u << edeg) - 1u) << (er0 & 31);
+        const char* lut = reinterpret_cast<const char*>(lds + TILE_MAIN_FLOATS);
+        using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(lut + 8 * ((mask >> (16 * s + 4 * hh)) & 15u));
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(lut + 8 * ((mask >> (16 * s + 8 + 4 * hh)) & 15u));
+            const u32x4 w = {lo[0], lo[1], hi[0], hi[1]};
+            sf[s] = __builtin_bit_cast(half8, w);
         }
-    f32x4 sum[4];
+    }
+    // 1 / (64 deg) per accumulator row: row n's factor sits in lane n; the accumulator rows of a lane are (r & 3) + 8 (r >> 2) + 4 hh
+    float* ftab = pl + wave * 32;            // the P rows are dead: every wave has passed the last barrier after its last gather
+    if (hh == 0) ftab[c] = (1.0f / ACT_SCALE) / (float)max(edeg, 1);
+    f32x4 fr[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sum[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q) fr[q] = *reinterpret_cast<const f32x4*>(ftab + 8 * q + 4 * hh);
 #pragma unroll
-    for (int rnd = 0; rnd < 2; ++rnd) {
-        TPROF(9);
-        __syncthreads();     // round 0: readers of the weight buffer and of the P / Q rows are done; round 1: the sums of round 0 are taken
-        TPROF(6);
-        if ((wave >> 1) == rnd) {
-            float* o = lds + ((wave & 1) * 32 + c) * LDR + 4 * hh;
+    for (int T = 0; T < 4; ++T) {
+        half8 mh[2], ml[2];
 #pragma unroll
-            for (int T = 0; T < 4; ++T)
+        for (int s = 0; s < 2; ++s) {
+            float v[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = f32x4{y[T][4 * q], y[T][4 * q + 1], y[T][4 * q + 2], y[T][4 * q + 3]};
+            for (int j = 0; j < 8; ++j) v[j] = y[T][8 * s + j];
+            split8(v, mh[s], ml[s]);
         }
-        TPROF(7);
-        __syncthreads();
-        TPROF(8);
-        const int lo_e = 64 * rnd, hi_e = 64 * rnd + 64;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r0 = max(r0b[k], lo_e), r1 = min(r1b[k], hi_e);       // this round's part of the node's rows (empty for nodes beyond the tile)
-            for (int rb = r0; rb < r1; rb += 8) {
-                f32x4 v[8];
+        for (int r = 0; r < 16; ++r) y[T][r] = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(lds + (min(rb + i, r1 - 1) - lo_e) * LDR + 4 * cq);
+        for (int s = 0; s < 2; ++s) {
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf[s], ml[s], y[T], 0, 0, 0);
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf[s], mh[s], y[T], 0, 0, 0);
+        }
+    }
+    TPROF(7);
+    // y[T][r] = 64 x (sum of the messages of target gf + acc_row(r, hh)), channel 32 T + c: scale and store 128-byte row pieces
+    {
+        const int ng = gl - gf;
+        float* out = a.agg + (size_t)gf * H + c;
+        bool bad = false;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float m = rb + i < r1 ? 1.0f : 0.0f;
+        for (int q = 0; q < 4; ++q) {
+            if (8 * q < ng) {                        // wave-uniform: rows 8 q .. 8 q + 7 hold targets
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) sum[k][x] = __builtin_fmaf(v[i][x], m, sum[k][x]);
+                for (int m = 0; m < 4; ++m) {
+                    const int row = 8 * q + 4 * hh + m;
+                    if (row < ng) {
+#pragma unroll
+                        for (int T = 0; T < 4; ++T) {
+                            const float v = y[T][4 * q + m] * fr[q][m];
+                            out[(size_t)row * H + 32 * T] = v;
+                            bad |= out_of_range(v);      // also NaN: an activation beyond fp16 upstream
+                        }
+                    }
                 }
             }
         }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int node = tile_n0 + nslot + 8 * k;
-        if (node < tile_n1) {
-            const int deg = r1b[k] - r0b[k];
-            const float invd = 1.0f / (float)max(deg, 1);
-            const f32x4 res = (sum[k] * post) * invd;
-            *reinterpret_cast<f32x4*>(a.agg + (size_t)node * H + 4 * cq) = res;
-            if (out_of_range(res)) status_raise(a.status, MSMP_STATUS_NODE_SATURATED);     // also NaN: an activation beyond fp16 upstream
-        }
+        if (bad) status_raise(a.status, MSMP_STATUS_NODE_SATURATED);
     }
     TPROF(9);
     TPROF_FLUSH
@@ -735,20 +763,28 @@ extern "C" int msmp_prepare_nodes(const void* x, int x_f64, const void* pos, int
     return check_launch("prepare_nodes_kernel");
 }
 
-extern "C" int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int64_t n_edges, int tile_nodes,
+extern "C" int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int64_t n_edges, int group_nodes,
                                 int32_t* tile_node_out, int32_t* tile_count_out, int32_t* tile_halo_out, int32_t* edge_slot_out,
                                 int32_t* stats_out, msmp_stream_t stream) {
     MSMP_REQUIRE(rowptr && col && tile_node_out && tile_count_out && tile_halo_out && edge_slot_out && stats_out, MSMP_ERR_ARG,
                  "msmp_build_tiles: null pointer");
     MSMP_REQUIRE(n_nodes > 0 && n_edges >= 0 && n_nodes < (1L << 31) && n_edges < (1L << 31), MSMP_ERR_ARG, "msmp_build_tiles: bad sizes");
-    MSMP_REQUIRE(tile_nodes >= 1 && tile_nodes <= MSMP_TILE_NCAP, MSMP_ERR_ARG, "msmp_build_tiles: tile_nodes must be in 1..%d", MSMP_TILE_NCAP);
+    MSMP_REQUIRE(group_nodes >= 1 && 4 * group_nodes <= MSMP_TILE_NCAP, MSMP_ERR_ARG, "msmp_build_tiles: group_nodes must be in 1..%d",
+                 MSMP_TILE_NCAP / 4);
     hipStream_t st = (hipStream_t)stream;
     const hipError_t me = hipMemsetAsync(stats_out, 0, 2 * sizeof(int32_t), st);
     MSMP_REQUIRE(me == hipSuccess, MSMP_ERR_HIP, "msmp_build_tiles: memset: %s", hipGetErrorString(me));
+    const int tile_nodes = 4 * group_nodes;
     const unsigned n_tiles = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
-    hipLaunchKernelGGL(build_tiles_kernel, dim3(n_tiles), dim3(128), 0, st, rowptr, col, (int)n_nodes, tile_nodes, tile_node_out,
+    hipLaunchKernelGGL(build_tiles_kernel, dim3(n_tiles), dim3(128), 0, st, rowptr, col, (int)n_nodes, tile_nodes, group_nodes, tile_node_out,
                        tile_count_out, tile_halo_out, edge_slot_out, stats_out);
     return check_launch("build_tiles_kernel");
+}
+
+// a caller-supplied descriptor is trusted for its pointers only: its geometry must cover exactly n_nodes
+static bool tiles_ok(const msmp_tiles_t* t, int64_t n_nodes) {
+    return t->tile_node && t->tile_count && t->tile_halo && t->edge_slot && t->group_nodes >= 1 && t->tile_nodes == 4 * t->group_nodes &&
+           t->tile_nodes <= MSMP_TILE_NCAP && (int64_t)t->n_tiles * t->tile_nodes >= n_nodes && (int64_t)(t->n_tiles - 1) * t->tile_nodes < n_nodes;
 }
 
 extern "C" int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, const float* pos, const float* vars, const float* feat,
@@ -759,17 +795,14 @@ extern "C" int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, con
     MSMP_REQUIRE((p != nullptr) == (q != nullptr), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: give both of p, q or neither");
     const bool fold = p == nullptr;
     MSMP_REQUIRE(!fold || (h && u && pos && vars), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: null pointer (h, u, pos, vars)");
-    MSMP_REQUIRE(tiles->tile_node && tiles->tile_count && tiles->tile_halo && tiles->edge_slot && tiles->tile_nodes >= 1 && tiles->tile_nodes <= MSMP_TILE_NCAP,
-                 MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: bad tile descriptor");
+    MSMP_REQUIRE(tiles_ok(tiles, n_nodes), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: the tile descriptor does not cover %ld nodes", (long)n_nodes);
     MSMP_REQUIRE(n_nodes > 0 && n_edges >= 0 && n_nodes < (1L << 31) && n_edges < (1L << 31) && tw > 0 && nv >= 1 && nv <= MSMP_MAX_VARS,
                  MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: bad sizes");
-    MSMP_REQUIRE((int64_t)tiles->n_tiles * tiles->tile_nodes >= n_nodes && (int64_t)(tiles->n_tiles - 1) * tiles->tile_nodes < n_nodes,
-                 MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: tile descriptor does not cover %ld nodes", (long)n_nodes);
     MSMP_REQUIRE(msmp_tune_get("split"), MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_f32: only on the fp16-split matrix path");
     const PackedLayout L = packed_layout(tw, nv);
     MSMP_REQUIRE(!fold || L.nc1 - 8 <= 2, MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_f32: tw + 1 + nv <= 64");
     TileArgs a{h, u, pos, vars, feat, p, q, rowptr, tiles->tile_node, tiles->tile_count, msmp_tune_get("tile_arith") ? tiles->tile_halo : nullptr, tiles->edge_slot, (long)n_nodes, (long)n_edges,
-               tiles->tile_nodes, tw, nv, L.nc1, packed + L.w1s, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, agg_out, status_ptr()};
+               tiles->tile_nodes, tiles->group_nodes, tw, nv, L.nc1, packed + L.w1s, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, agg_out, status_ptr()};
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_EDGE_MLP, st);
     const dim3 grid(tile_grid(tiles->n_tiles, 1));
@@ -786,9 +819,7 @@ int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* 
                                    const float* packed_b, float* agg_a, float* agg_b, msmp_stream_t stream) {
     MSMP_REQUIRE(h && u && pos && vars && rowptr && tiles && packed_a && packed_b && agg_a && agg_b, MSMP_ERR_ARG,
                  "msmp_edge_aggregate_tiled_pair: null pointer");
-    MSMP_REQUIRE(tiles->tile_node && tiles->tile_count && tiles->tile_halo && tiles->edge_slot && tiles->tile_nodes >= 1 && tiles->tile_nodes <= MSMP_TILE_NCAP &&
-                 (int64_t)tiles->n_tiles * tiles->tile_nodes >= n_nodes && (int64_t)(tiles->n_tiles - 1) * tiles->tile_nodes < n_nodes,
-                 MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_pair: tile descriptor does not cover %ld nodes", (long)n_nodes);
+    MSMP_REQUIRE(tiles_ok(tiles, n_nodes), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_pair: the tile descriptor does not cover %ld nodes", (long)n_nodes);
     const PackedLayout L = packed_layout(tw, nv);
     MSMP_REQUIRE(L.nc1 - 8 <= 2 && msmp_tune_get("split"), MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_pair: unsupported configuration");
     TileArgs2 a2;
@@ -796,7 +827,7 @@ int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* 
     float* agg[2] = {agg_a, agg_b};
     for (int i = 0; i < 2; ++i)
         a2.head[i] = TileArgs{h, u, pos, vars, feat, nullptr, nullptr, rowptr, tiles->tile_node, tiles->tile_count, msmp_tune_get("tile_arith") ? tiles->tile_halo : nullptr, tiles->edge_slot, (long)n_nodes,
-                              (long)n_edges, tiles->tile_nodes, tw, nv, L.nc1, packed[i] + L.w1s, packed[i] + L.w2s, packed[i] + L.scales,
+                              (long)n_edges, tiles->tile_nodes, tiles->group_nodes, tw, nv, L.nc1, packed[i] + L.w1s, packed[i] + L.w2s, packed[i] + L.scales,
                               packed[i] + L.b1, packed[i] + L.b2, agg[i], status_ptr()};
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_EDGE_MLP, st);

@@ -72,36 +72,38 @@ class GraphStructure(object):
 
     def tiles(self):
         """Node tiles of the LDS-staged message kernel (msmp_tiles_t; include/msmp_pde.h), built once per structure; None when
-        the graph does not tile (a tile of target nodes would touch more than MSMP_TILE_NCAP distinct nodes, or carry more than
-        MSMP_TILE_EDGES edges, unless it became too small to pay off): the callers then take the gather kernels.
-        tile_nodes: as many consecutive targets as fit 128 edges at the largest in-degree, then shrunk by the halo the first
-        attempt reported (banded graphs have a near-constant halo: a few retries, one device read-back each)."""
+        the graph does not tile (in-degrees above 32: a target's in-edges must fit the 32 lanes of one wave; or a tile of target
+        nodes would touch more than MSMP_TILE_NCAP distinct nodes unless it became too small to pay off): the callers then take
+        the gather kernels.  group_nodes: as many consecutive targets as fit a wave's 32 edge lanes at the largest in-degree (at
+        most 8: four groups share the 32 node slots), then shrunk while the tiles' node lists do not fit (banded graphs have a
+        near-constant halo: a few retries, one device read-back each)."""
         if self._tiles is not False:
             return self._tiles
         self._tiles = None
-        if self.n_edges == 0 or self.max_in_degree <= 0 or self.max_in_degree > _lib.MSMP_TILE_EDGES:
+        if self.n_edges == 0 or self.max_in_degree <= 0 or self.max_in_degree > _lib.MSMP_TILE_GROUP_EDGES:
             return None
         L = lib()
         dev = self.rowptr.device
-        tn0 = min(_lib.MSMP_TILE_NCAP, _lib.MSMP_TILE_EDGES // self.max_in_degree)
-        tn = tn0
+        gn0 = min(_lib.MSMP_TILE_NCAP // 4, _lib.MSMP_TILE_GROUP_EDGES // self.max_in_degree)
+        gn = gn0
         for _attempt in range(4):
-            if tn < max(4, tn0 // 2):           # tiles this small waste the 128-edge block: not worth it
+            if gn < max(1, gn0 // 2):           # tiles this small waste the 128-lane block: not worth it
                 return None
+            tn = 4 * gn
             n_tiles = (self.n_nodes + tn - 1) // tn
             tile_node = torch.empty(n_tiles * _lib.MSMP_TILE_NCAP, dtype=torch.int32, device=dev)
             tile_count = torch.empty(n_tiles, dtype=torch.int32, device=dev)
             tile_halo = torch.empty(n_tiles * 4, dtype=torch.int32, device=dev)
             edge_slot = torch.empty(n_tiles * _lib.MSMP_TILE_EDGES, dtype=torch.int32, device=dev)
             stats = torch.empty(2, dtype=torch.int32, device=dev)
-            check(L.msmp_build_tiles(ptr(self.rowptr), ptr(self.col), self.n_nodes, self.n_edges, tn, ptr(tile_node), ptr(tile_count),
+            check(L.msmp_build_tiles(ptr(self.rowptr), ptr(self.col), self.n_nodes, self.n_edges, gn, ptr(tile_node), ptr(tile_count),
                                      ptr(tile_halo), ptr(edge_slot), ptr(stats), current_stream()), 'msmp_build_tiles')
             max_nodes, max_edges = (int(v) for v in stats.tolist())
-            if max_nodes <= _lib.MSMP_TILE_NCAP and max_edges <= _lib.MSMP_TILE_EDGES:
-                desc = _lib.MsmpTiles(tn, n_tiles, ptr(tile_node), ptr(tile_count), ptr(tile_halo), ptr(edge_slot))
+            if max_nodes <= _lib.MSMP_TILE_NCAP and max_edges <= _lib.MSMP_TILE_GROUP_EDGES:
+                desc = _lib.MsmpTiles(tn, gn, n_tiles, ptr(tile_node), ptr(tile_count), ptr(tile_halo), ptr(edge_slot))
                 self._tiles = (desc, tile_node, tile_count, edge_slot, tile_halo)      # the tensors keep the descriptor's memory alive
                 return self._tiles
-            tn = min(tn - 1, tn - (max_nodes - _lib.MSMP_TILE_NCAP)) if max_nodes > _lib.MSMP_TILE_NCAP else tn - 1
+            gn -= max(1, -(-(max_nodes - _lib.MSMP_TILE_NCAP) // 4)) if max_nodes > _lib.MSMP_TILE_NCAP else 1
         return None
 
     @property

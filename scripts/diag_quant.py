@@ -219,3 +219,57 @@ def main_acc(exp):
 
 if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == 'acc':
     main_acc(sys.argv[1])
+
+
+# ---- third experiment (python scripts/diag_quant.py E2 center): update_net_2 / update_net_1 on differences to a reference node ---
+def layer_center(p, h, u, pos, var, ei, batch, modes, c4, c3):
+    j, i = ei[0], ei[1]
+    tw = u.shape[1]
+    feat = np.concatenate((u, pos, var), 1)
+    fq = feat.copy(); fq[:, tw + 1:] = 0.0
+    m = lambda k: modes.get(k, '0')
+    P = mfma_gemm(np.concatenate((h, feat), 1), np.concatenate((p.w1[:, :128], p.w1[:, 256:]), 1), p.b1, 256.0, m('w1'))
+    Qn = mfma_gemm(np.concatenate((h, -fq), 1), np.concatenate((p.w1[:, 128:256], p.w1[:, 256:]), 1), 0.0 * p.b1, 256.0, m('w1'))
+    msg = O.swish(mfma_gemm(O.swish(P[i] + Qn[j]), p.w2, p.b2, 64.0, m('w2')))
+    agg = O.scatter_mean(msg, i, h.shape[0])
+    x = np.concatenate((h, agg, var), 1)
+    first = np.concatenate(([0], np.flatnonzero(batch[1:] != batch[:-1]) + 1))
+    ref = first[batch]                                    # first node of each node's graph
+    if c3:      # pre_n = pre_ref + W3 (x_n - x_ref): ONE fp32 rounding at full magnitude instead of 50
+        pre_ref = mfma_gemm(x[first], p.w3, p.b3, 256.0, m('w3'))[batch]
+        d = mfma_gemm((x - x[ref]).astype(np.float32).astype(np.float64), p.w3, 0.0 * p.b3, 256.0, m('w3'))
+        pre = (pre_ref + d).astype(np.float32).astype(np.float64)
+    else:
+        pre = mfma_gemm(x, p.w3, p.b3, 256.0, m('w3'))
+    z = O.swish(pre)
+    if c4:
+        return mfma_gemm((z - z[ref]).astype(np.float32).astype(np.float64), p.w4, 0.0 * p.b4, 64.0, m('w4'))
+    return mfma_gemm(z, p.w4, p.b4, 64.0, m('w4'))
+
+
+def main_center(exp):
+    torch.manual_seed(3)
+    case = synthetic_case(mp, exp, bsz=8, seed=11, device='cpu')
+    kind = 'MP_PDE_SolverLEMLinGated'
+    model = getattr(mp, kind)(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=6)
+    sd = {k: v.detach().numpy().astype(np.float64) for k, v in model.state_dict().items()}
+    g = case.graph_np()
+    r64 = O.solver_forward(kind, sd, g, case.pde, TW, case.eqv, 6, parts=True)
+    u = np.asarray(g.x, dtype=np.float64)
+    pos_x, pos_t, var = O.build_variables(kind, g, case.pde, case.eqv)
+    ei, batch = np.asarray(g.edge_index), np.asarray(g.batch)
+    all3 = {k: '3' for k in ('w1', 'w2', 'w3', 'w4')}
+    for li in (0, 1, 3):
+        hin = r64.hs[li - 1] if li else r64.h_enc
+        ref = r64.hs[li]
+        pg, pm = O.layer_params(sd, f'gnn_layers_gate.{li}.'), O.layer_params(sd, f'gnn_layers.{li}.')
+        print(f'layer pair {li}')
+        for name, c4, c3 in (('shipped before round 3', False, False), ('update_net_2 centred (round 3)', True, False),
+                             ('update_net_2 and update_net_1 centred', True, True)):
+            tau = O.sigmoid(O.instance_norm(layer_center(pg, hin, u, pos_x, var, ei, batch, all3, c4, c3), batch))
+            out = (1.0 - tau) * hin + tau * O.swish(O.instance_norm(layer_center(pm, hin, u, pos_x, var, ei, batch, all3, c4, c3), batch))
+            print(f'    {name:45s} rms {np.sqrt(np.mean((out - ref) ** 2)):.2e}  max {np.abs(out - ref).max():.2e}')
+
+
+if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == 'center':
+    main_center(sys.argv[1])

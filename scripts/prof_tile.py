@@ -26,8 +26,8 @@ tiles = gs.tiles(); tb = ctypes.byref(tiles[0])
 from msmp_pde_amd.layers import node_features
 FEAT = node_features(u, pos, var)
 names = ['prologue: index + row loads, staging, barrier', 'projection MFMAs (fold)', 'barrier, P/Q to LDS, barrier (fold)', 'first activation step + gathers',
-         'K = 16 step: MFMAs + activation of next (x8)', 'step: weight store + barrier (x7)', 'epilogue barrier A (x2)', 'epilogue swish + stage (x2, two waves each)',
-         'epilogue barrier B (x2)', 'segmented mean (x2) + store']
+         'K = 16 step: MFMAs + activation of next (x8)', 'step: weight store + barrier (x7)', 'epilogue: Swish of the messages', 'epilogue: selection matrix, split, mean MFMAs',
+         '(unused)', 'epilogue: scale + store']
 for fold in (False, True):
     args = (ptr(h), ptr(u), ptr(pos), ptr(var), ptr(FEAT), None, None) if fold else (None, None, None, None, None, ptr(P), ptr(Q))
     run = lambda: _lib.check(L.msmp_edge_aggregate_tiled_f32(*args, ptr(gs.rowptr), tb, n, e, 25, 2, ptr(packed), ptr(agg), cs()), 'tiled')

@@ -81,4 +81,14 @@ def test_full_size_batch_properties(mp, kind, exp, layers):
     with torch.no_grad():
         out_p = model(graph_p)
     want = out.view(B, nx, -1)[perm.cuda()].reshape(out.shape)
-    assert (out_p - want).abs().max().item() < (1e-6 if '2D' in kind else 0.0 + 1e-6)
+    # Node tiles that divide a graph (E2, MSWG3: 20 of 100 nodes) put every graph's edges at the same lanes of the message kernel's
+    # wave groups wherever the graph sits in the batch: identical arithmetic, identical bits.  Otherwise (WE3, RPU tiles of 28 /
+    # 20 nodes straddle graphs) a target's <= 32 messages are summed by the MFMA at other K positions: same values, another fp32
+    # rounding order, amplified by the untrained network like any rounding difference -- held to the float32 floor instead.
+    from msmp_pde_amd.graph import structure_of
+    from helpers import err_stats
+    tiles = structure_of(graph).tiles()
+    aligned = tiles is None or nx % tiles[0].tile_nodes == 0
+    floor_max = max(err_stats(v, ref)[0] for v in floor.values())
+    tol = 1e-6 if aligned else max(1e-5, 2.0 * floor_max)
+    assert (out_p - want).abs().max().item() < tol, (aligned, tol)

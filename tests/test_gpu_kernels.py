@@ -577,15 +577,17 @@ def _tile_case(mp, exp, bsz, nx=100, neighbors=3, seed=3):
 @pytest.mark.parametrize('exp,bsz,nx,neighbors', [('E2', 5, 100, 3), ('WE3', 4, 100, 3), ('RPU', 3, 100, 3), ('MSWG3', 2, 100, 8),
                                                   ('E2', 7, 40, 3), ('E2', 1, 100, 2)])
 def test_node_tiles_are_a_valid_cover(mp, exp, bsz, nx, neighbors):
-    """msmp_build_tiles: every tile lists its target nodes first, then each further source exactly once; every edge's slot pair
-    points at its own target / source; lists stay within MSMP_TILE_NCAP and MSMP_TILE_EDGES (checked against a numpy rebuild)."""
+    """msmp_build_tiles: every tile lists its target nodes first, then each further source exactly once; the in-edges of wave
+    group g (group_nodes consecutive targets) sit at lanes 32 g ..., in CSR order, at most 32 of them; every edge's slot pair
+    points at its own target / source; lists stay within MSMP_TILE_NCAP (checked against a numpy rebuild)."""
     from msmp_pde_amd import _lib
     c, graph, gs = _tile_case(mp, exp, bsz, nx, neighbors)
     t = gs.tiles()
     assert t is not None, 'the banded 1-D graphs of the four experiments must tile'
     desc, tile_node, tile_count, edge_slot, tile_halo = t
     tile_halo = tile_halo.cpu().numpy().reshape(-1, 4)
-    tn, n_tiles = desc.tile_nodes, desc.n_tiles
+    tn, gn, n_tiles = desc.tile_nodes, desc.group_nodes, desc.n_tiles
+    assert tn == 4 * gn
     rowptr, col = gs.rowptr.cpu().numpy(), gs.col.cpu().numpy()[:gs.n_edges]
     tile_node = tile_node.cpu().numpy().reshape(n_tiles, _lib.MSMP_TILE_NCAP)
     tile_count, edge_slot = tile_count.cpu().numpy(), edge_slot.cpu().numpy().reshape(n_tiles, _lib.MSMP_TILE_EDGES)
@@ -593,24 +595,30 @@ def test_node_tiles_are_a_valid_cover(mp, exp, bsz, nx, neighbors):
     for ti in range(n_tiles):
         n0, n1 = ti * tn, min((ti + 1) * tn, gs.n_nodes)
         e0, e1 = rowptr[n0], rowptr[n1]
-        assert e1 - e0 <= _lib.MSMP_TILE_EDGES and tile_count[ti] <= _lib.MSMP_TILE_NCAP
+        assert tile_count[ti] <= _lib.MSMP_TILE_NCAP
         nodes = tile_node[ti]
         assert np.array_equal(nodes[:n1 - n0], np.arange(n0, n1))
         extra = nodes[n1 - n0:tile_count[ti]]
         assert len(set(extra.tolist())) == len(extra) and not np.any((extra >= n0) & (extra < n1))
         assert set(extra.tolist()) == set(col[e0:e1][(col[e0:e1] < n0) | (col[e0:e1] >= n1)].tolist())
         assert np.all((nodes >= 0) & (nodes < gs.n_nodes))
-        tgt_of_edge = np.searchsorted(rowptr, np.arange(e0, e1), side='right') - 1
-        assert np.array_equal(n0 + (edge_slot[ti, :e1 - e0] & 255), tgt_of_edge)
-        assert np.array_equal(nodes[(edge_slot[ti, :e1 - e0] >> 8) & 255], col[e0:e1])
-        assert not edge_slot[ti, e1 - e0:].any()
+        for g in range(4):
+            gf = min(n0 + g * gn, n1)
+            gl = min(gf + gn, n1)
+            ge0, ge1 = rowptr[gf], rowptr[gl]
+            assert ge1 - ge0 <= 32
+            lanes = edge_slot[ti, 32 * g:32 * g + (ge1 - ge0)]
+            tgt_of_edge = np.searchsorted(rowptr, np.arange(ge0, ge1), side='right') - 1
+            assert np.array_equal(n0 + (lanes & 255), tgt_of_edge)
+            assert np.array_equal(nodes[(lanes >> 8) & 255], col[ge0:ge1])
+            assert not edge_slot[ti, 32 * g + (ge1 - ge0):32 * g + 32].any()
         lo, nlo, hi, nhi = tile_halo[ti]
         if nlo >= 0:        # ranged tile: the list is [targets | lo run | hi run], which the kernel reproduces arithmetically
             want = np.concatenate([np.arange(n0, n1), np.arange(lo, lo + nlo), np.arange(hi, hi + nhi)])
             assert np.array_equal(nodes[:tile_count[ti]], want)
     if exp in ('E2', 'MSWG3', 'WE3'):
         assert (tile_halo[:, 1] >= 0).all(), 'every tile of a banded graph without wrap-around is ranged'
-    print(f'{exp}: {int((tile_halo[:, 1] >= 0).sum())} of {n_tiles} tiles ranged, tile_nodes {tn}')
+    print(f'{exp}: {int((tile_halo[:, 1] >= 0).sum())} of {n_tiles} tiles ranged, tile_nodes {tn} (4 groups of {gn})')
 
 
 def test_irregular_graph_does_not_tile(mp):
