@@ -17,14 +17,17 @@ SOURCES = {  # file -> extra flags
     'tile_kernels.hip': [],
     'aux_kernels.hip': [],
     # MFMA results stay in VGPRs (the activations read them with VALU; the stationary weights take the AGPRs)
-    'lem_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
+    # -fno-slp-vectorize: the anti-phased kernel's state update stays UNPACKED fp32 (a packed-fp32 instruction beside the partner
+    # wave's MFMAs costs more cycles than the two instructions it replaces: 2 480 vs 1 960 cycles per vector half, scripts/prof_lem.py;
+    # the SLP vectoriser would re-pack the scalar ops)
+    'lem_kernel.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form', '-fno-slp-vectorize'],
     'lem_train_kernel.hip': [],
     'train_kernels.hip': [],
     'mlp2_kernel.hip': [],
     'decoder_kernel.hip': [],
     'graph_kernels.hip': ['-ffp-contract=off'],   # float64 distance compares must round like the host's
 }
-PROF = {'tile': ['-DMSMP_PROF_TILE=1'], '1': ['-DMSMP_PROF=1'], 'edge': ['-DMSMP_PROF=1', '-DMSMP_PROF_EDGE=1'], 'proj': ['-DMSMP_PROF=1', '-DMSMP_PROF_PROJ=1']}.get(os.environ.get('MSMP_PROF', ''), [])     # phase counters in the tail kernel (scripts/prof_tail.py)
+PROF = {'lem': ['-DMSMP_PROF_LEM=1'], 'tile': ['-DMSMP_PROF_TILE=1'], '1': ['-DMSMP_PROF=1'], 'edge': ['-DMSMP_PROF=1', '-DMSMP_PROF_EDGE=1'], 'proj': ['-DMSMP_PROF=1', '-DMSMP_PROF_PROJ=1']}.get(os.environ.get('MSMP_PROF', ''), [])     # phase counters in the tail kernel (scripts/prof_tail.py)
 COMMON = PROF + ([f'-DMSMP_LOLO={LOLO}'] if LOLO else []) + ([f'-DMSMP_TILE_VARIANT={VARIANT}'] if VARIANT else []) + (['-DMSMP_PRECISE_ACT=1'] if PRECISE else []) + ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
           '-fvisibility=hidden', '-fvisibility-inlines-hidden',
           '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
@@ -41,6 +44,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(ROOT, 'include', 'msmp_pde.h'))
+    headers.append(os.path.abspath(__file__))          # the flags live here
     objs = []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)

@@ -17,6 +17,7 @@
 // the step inputs are read from a row padded to 2*NS floats, so the time loop is branch-free).  Algorithmic work: T * 2*(H+ninp)*4H + 2*2*H*H FLOP per node
 // = 3.44 MFLOP per node at T = 25, ninp = 4 (705 GFLOP for 2048 E2 graphs): MFMA-bound.
 #include "lem_layout.h"
+#include <type_traits>
 
 namespace msmp {
 
@@ -823,6 +824,46 @@ __device__ __forceinline__ void lem_ws_update_publish(const f32x16& a0, const f3
     }
 }
 
+// The state update of the anti-phased kernel: plain (unpacked) fp32 instructions.  Its vector halves run BESIDE the partner wave's
+// MFMAs, where a packed-fp32 instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32) waits for the matrix pipe: measured 2 700
+// cycles per vector half with the packed form of lem_ws_update_publish against 1 500 for the matrix half (scripts/prof_lem.py).
+// Two value pairs per stage (half the live temporaries of lem_ws_update_publish: this kernel keeps a work item's accumulators
+// across a barrier and one more state tile).
+__device__ __forceinline__ void lem_ws_update_publish_q(const f32x16& a0, const f32x16& a1, const LemActConst& k, f32x16& st,
+                                                        half8* area, int ks, int lane) {
+    const float c0 = k.c0[0], c1 = k.c1[0], idt = k.idt[0];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        half8 phi, plo;
+        // eight independent value pipelines, no staging barriers: the scheduler interleaves them within the registers it has
+        // (a dependent VALU instruction issues 8 cycles after its producer, an independent one after 4.4: scripts/micro/valu_issue.hip)
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            f32x2 sv;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 8 * s + i + e;
+                const float ea = msmp_exp2(a0[r] * c0);
+                const float eb = msmp_exp2(vmin(a1[r] * c1, 60.f));
+                const float qb = eb + 1.0f;
+                const float rr = msmp_rcp(__builtin_fmaf(ea, idt, idt) * qb);
+                sv[e] = __builtin_fmaf(rr, __builtin_fmaf(-st[r], qb, 1.0f - eb), st[r]);
+                st[r] = sv[e];
+            }
+            const half2 hp = __builtin_convertvector(sv, half2);
+            const half2 lp = split_lo_pair(hp, sv);
+            phi[i] = hp[0];
+            phi[i + 1] = hp[1];
+            plo[i] = lp[0];
+            plo[i + 1] = lp[1];
+        }
+        area[((ks * 2 + s) * 2 + 0) * 64 + lane] = phi;
+        area[((ks * 2 + s) * 2 + 1) * 64 + lane] = plo;
+    }
+}
+
+// sched_barrier mask: everything may cross except MFMAs (and the catch-all ALU class that contains them)
+constexpr int LEM_SCHED_NOT_MFMA = 0x7F6;
 // acc0 += W0 B0, acc1 += W1 B1 over K = 128 (B0/B1: published fragment areas; they may be the same area)
 template <bool SAME>
 __device__ __forceinline__ void lem_ws_gemm2(const half8 (&w0)[4][2][2], const half8 (&w1)[4][2][2], const half8* b0, const half8* b1,
@@ -844,9 +885,11 @@ __device__ __forceinline__ void lem_ws_gemm2(const half8 (&w0)[4][2][2], const h
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][1], h0, acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][0], l0, acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][0], h0, acc0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(LEM_SCHED_NOT_MFMA);      // left alone the scheduler alternates acc0 / acc1 when both read the same fragments
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kt][s][1], h1, acc1, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kt][s][0], l1, acc1, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kt][s][0], h1, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(LEM_SCHED_NOT_MFMA);
         }
 }
 
@@ -1023,6 +1066,300 @@ __global__ __launch_bounds__(512) void lem_encoder_ws_kernel(LemWsArgs a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// WEIGHT-STATIONARY, ANTI-PHASED edition (default since round 3; msmp_tune("lem", 4)).  Same roles, registers and LDS traffic as
+// lem_encoder_ws_kernel, but a workgroup carries THREE node tiles (96 nodes) and every work item is cut into its matrix half M
+// (input MFMAs + the two gate GEMMs: 50 MFMAs, accumulators kept in registers) and its vector half V (state update + publish),
+// one barrier per half.  The two waves of a SIMD are wave (ks, A) and wave (ks, B); in the two-tile pipeline both ran their
+// GEMMs right after the stage's barrier and their activations afterwards -- matrix beside matrix, vector beside vector on
+// every SIMD: 6.7 k cycles per stage for 3.2 k cycles of matrix work (rocprofv3 SQ counters, profiles/r03c_*).  Here, per time
+// step t and slot j = 0..5:
+//     role A:  M(0,t)    V(0,t)     M(1,t)     V(1,t)   M(2,t)   V(2,t)
+//     role B:  V(1,t-1)  M(2,t-1)   V(2,t-1)   M(0,t)   V(0,t)   M(1,t)
+// so one wave of every SIMD is in a matrix half while the other is in a vector half.  Dependencies (A's V(X,t) publishes
+// z_X(t+1), read by B's M(X,t); B's V(X,t) publishes y_X(t+1), read by A's M(X,t+1) and B's M(X,t+1)) are each separated by
+// at least one barrier, and every buffer's last reader precedes its next writer by a barrier, so y needs ONE buffer per tile.
+// ----------------------------------------------------------------------------------------------
+#if MSMP_PROF_LEM
+__device__ unsigned long long g_prof_lem[16];
+#define LPROF_DECL unsigned lp_m = 0, lp_v = 0, lp_b = 0, lp_w = 0, lp_t = (unsigned)__builtin_readcyclecounter();
+#define LPROF(var) do { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); var += t_ - lp_t; lp_t = t_; } while (0)
+#define LPROF_FLUSH if (lane == 0 && ks == 0 && (blockIdx.x & 31) == 0) { unsigned long long* o = g_prof_lem + 4 * role; atomicAdd(o, (unsigned long long)lp_m); atomicAdd(o + 1, (unsigned long long)lp_v); atomicAdd(o + 2, (unsigned long long)lp_b); atomicAdd(o + 3, 1ull); atomicAdd(g_prof_lem + 8 + role, (unsigned long long)lp_w); }
+#else
+#define LPROF_DECL unsigned lp_w = 0; (void)lp_w;
+#define LPROF(var)
+#define LPROF_FLUSH
+#endif
+#define LEM_SYNC() do { LPROF(lp_w); __syncthreads(); LPROF(lp_b); } while (0)
+
+// lem_ws_gemm2 with every fragment address formed as  byte base (a __shared__ array)  +  ONE opaque per-lane register  +  a
+// compile-time offset that fits ds_read's 16-bit field: left to itself the compiler hoists the ~100 distinct fragment addresses of
+// the unrolled time step out of the loop as invariants and spills them (scratch reloads with vmcnt(0) waits between the MFMAs).
+template <bool SAME, int OFF0, int OFF1>
+__device__ __forceinline__ void lem_ws3_gemm2(const half8 (&w0)[4][2][2], const half8 (&w1)[4][2][2], const char* b0, const char* b1,
+                                              f32x16& acc0, f32x16& acc1) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            constexpr int FB = 64 * 16;       // bytes of one fragment plane
+            const int f = (kt * 2 + s) * 2;
+            const half8 h0 = *reinterpret_cast<const half8*>(b0 + OFF0 + f * FB), l0 = *reinterpret_cast<const half8*>(b0 + OFF0 + (f + 1) * FB);
+            half8 h1 = h0, l1 = l0;
+            if (!SAME) {
+                h1 = *reinterpret_cast<const half8*>(b1 + OFF1 + f * FB);
+                l1 = *reinterpret_cast<const half8*>(b1 + OFF1 + (f + 1) * FB);
+            }
+            MSMP_MFMA_LOLO(2, acc0, w0[kt][s][1], l0);
+            MSMP_MFMA_LOLO(2, acc1, w1[kt][s][1], l1);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][1], h0, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][0], l0, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][0], h0, acc0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(LEM_SCHED_NOT_MFMA);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kt][s][1], h1, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kt][s][0], l1, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kt][s][0], h1, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(LEM_SCHED_NOT_MFMA);
+        }
+}
+
+template <int P, int MODE>
+__global__ __launch_bounds__(512) void lem_encoder_ws3_kernel(LemWsArgs a) {
+    constexpr int NS = (P + 1) / 2, M = (3 * P + 2 + 15) / 16;
+    // y fragments [tile 3] | z fragments [tile 3] (16 KB each) | scaled biases [512 + 256]
+    __shared__ __attribute__((aligned(16))) float lds[6 * SPLIT_CHUNK_FLOATS + 768];
+    __shared__ __attribute__((aligned(16))) float xconst[96 * 8];
+    // the input-column fragments (W[:, H:] and the bias slots) of every wave: kept out of the register file, which holds the
+    // recurrent weights (128), three state tiles (48) and a work item's accumulators (32)
+    __shared__ half8 wxl[8 * 2 * M * 64];
+    half8* const yfr = reinterpret_cast<half8*>(lds);
+    half8* const zfr = yfr + 3 * LEM_WS_FR;
+    float* const bias_l = lds + 6 * SPLIT_CHUNK_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: the role branches become scalar branches
+    const int ks = wave & 3, role = wave >> 2;
+    const int c = lane & 31, hh = lane >> 5;
+    const long n0 = (long)blockIdx.x * 96;
+    const float LOG2E = 1.44269504088896340736f;
+    const float inv_w = a.scales[4], inv_z = a.scales[5];
+    const int T = a.t_len;
+
+    {   // prologue: y(0) = 0 for the three tiles, biases, per-node constants
+        half8 zero;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zero[j] = (_Float16)0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) yfr[tid + 512 * i] = zero;
+        bias_l[tid] = a.bias_s[tid];
+        if (tid < 256) bias_l[512 + tid] = a.mlpb_s[tid];
+        if (MODE != 0 && tid < 96) {
+            const long nn = n0 + tid < a.n_nodes ? n0 + tid : a.n_nodes - 1;
+            float* row = xconst + 8 * tid;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) row[f] = 0.f;
+            row[0] = a.pos_x[nn];
+            if (MODE == 1) {
+                for (int f = 0; f < a.nv; ++f) row[2 + f] = a.vars[(size_t)nn * a.nv + f];
+            } else {
+                row[3] = a.pos_t[nn];
+                for (int f = 1; f < a.nv; ++f) row[3 + f] = a.vars[(size_t)nn * a.nv + f];
+            }
+        }
+    }
+    half8 w[2][4][2][2];
+    half8* const wxw = wxl + (size_t)wave * (2 * M * 64) + lane;       // this wave's: [gate 2][m M][lane 64]
+    {
+        const half8* rs = reinterpret_cast<const half8*>(a.rec_s);
+        const half8* wh = reinterpret_cast<const half8*>(a.wx_h);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int grp = 2 * role + gi;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        w[gi][kt][s][pl] = rs[(size_t)(grp * 4 + kt) * 1024 + ((s * 4 + ks) * 2 + pl) * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < M; ++m) wxw[(gi * M + m) * 64] = wh[((grp * 4 + ks) * 2 + m) * 64 + lane];
+        }
+    }
+    const float c0 = -inv_w * LOG2E, c1 = -2.0f * (role ? inv_z : inv_w) * LOG2E, idt = 1.0f / a.dt;
+    const LemActConst kc{f32x2{c0, c0}, f32x2{c1, c1}, f32x2{idt, idt}, f32x2{1.0f, 1.0f}};
+
+    f32x16 st[3];
+#pragma unroll
+    for (int X = 0; X < 3; ++X)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[X][r] = 0.f;
+    // LDS fragment addressing: two opaque per-lane byte addresses (y area; z area, beyond ds_read's 64-KB offset field) + constants
+    constexpr int ZBASE = 3 * LEM_WS_FR * 16;
+    const char* lb_y;
+    const char* lb_z;
+    {
+        unsigned lo = lane * 16;
+        asm volatile("" : "+v"(lo));
+        lb_y = reinterpret_cast<const char*>(lds) + lo;
+        unsigned lo2 = lane * 16 + ZBASE;
+        asm volatile("" : "+v"(lo2));
+        lb_z = reinterpret_cast<const char*>(lds) + lo2;
+    }
+    float xn[2 * NS];
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    __syncthreads();                    // the constants table and y(0) are read below
+
+    // the two halves of a work item; X is a compile-time tile index
+    auto fetch_x = [&](auto Xc, int t) {
+        constexpr int X = decltype(Xc)::value;
+        const long n = n0 + 32 * X + c;
+        lem_ws_load_x<P, MODE>(a, xconst + 8 * (32 * X + c), n < a.n_nodes ? n : a.n_nodes - 1, t, xn);
+    };
+    auto half_m = [&](auto Xc) {
+        constexpr int X = decltype(Xc)::value;
+        half8 bx[M];
+        lem_ws_slots<P>(xn, hh, bx);
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxw[0], bx[0], zero, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxw[M * 64], bx[0], zero, 0, 0, 0);
+#pragma unroll
+        for (int m = 1; m < M; ++m) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxw[m * 64], bx[m], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxw[(M + m) * 64], bx[m], acc1, 0, 0, 0);
+        }
+        constexpr int YO = X * LEM_WS_FR * 16, ZO = (3 + X) * LEM_WS_FR * 16 - ZBASE;
+        if (role) lem_ws3_gemm2<false, YO, ZO>(w[0], w[1], lb_y, lb_z, acc0, acc1);
+        else lem_ws3_gemm2<true, YO, YO>(w[0], w[1], lb_y, lb_y, acc0, acc1);
+    };
+    auto half_v = [&](auto Xc) {
+        constexpr int X = decltype(Xc)::value;
+        lem_ws_update_publish_q(acc0, acc1, kc, st[X], (role ? yfr : zfr) + X * LEM_WS_FR, ks, lane);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+
+    LPROF_DECL
+    // Two separate instruction streams (the role is wave-uniform): each executes 6 T + 3 barriers.
+    if (!role) {
+        fetch_x(I0{}, 0);
+        for (int t = 0; t < T; ++t) {
+            { half_m(I0{}); LPROF(lp_m); }                                           LEM_SYNC();      // slot 0
+            fetch_x(I1{}, t); { half_v(I0{}); LPROF(lp_v); }                         LEM_SYNC();      // slot 1
+            { half_m(I1{}); LPROF(lp_m); }                                           LEM_SYNC();      // slot 2
+            fetch_x(I2{}, t); { half_v(I1{}); LPROF(lp_v); }                         LEM_SYNC();      // slot 3
+            { half_m(I2{}); LPROF(lp_m); }                                           LEM_SYNC();      // slot 4
+            fetch_x(I0{}, t + 1 < T ? t + 1 : t); { half_v(I2{}); LPROF(lp_v); }     LEM_SYNC();      // slot 5
+        }
+        LEM_SYNC();
+        LEM_SYNC();
+        LEM_SYNC();
+    } else {
+        // t = 0: slots 0-2 have no work yet (the items of step -1)
+        LEM_SYNC();
+        LEM_SYNC();
+        fetch_x(I0{}, 0);                                           LEM_SYNC();
+        { half_m(I0{}); LPROF(lp_m); }                                               LEM_SYNC();      // slot 3
+        fetch_x(I1{}, 0); { half_v(I0{}); LPROF(lp_v); }                             LEM_SYNC();      // slot 4
+        { half_m(I1{}); LPROF(lp_m); }                                               LEM_SYNC();      // slot 5
+        for (int t = 1; t < T; ++t) {
+            fetch_x(I2{}, t - 1); { half_v(I1{}); LPROF(lp_v); }                     LEM_SYNC();      // slot 0: V(1, t-1)
+            { half_m(I2{}); LPROF(lp_m); }                                           LEM_SYNC();      // slot 1: M(2, t-1)
+            fetch_x(I0{}, t); { half_v(I2{}); LPROF(lp_v); }                         LEM_SYNC();      // slot 2: V(2, t-1)
+            { half_m(I0{}); LPROF(lp_m); }                                           LEM_SYNC();      // slot 3: M(0, t)
+            fetch_x(I1{}, t); { half_v(I0{}); LPROF(lp_v); }                         LEM_SYNC();      // slot 4: V(0, t)
+            { half_m(I1{}); LPROF(lp_m); }                                           LEM_SYNC();      // slot 5: M(1, t)
+        }
+        fetch_x(I2{}, T - 1); { half_v(I1{}); LPROF(lp_v); }                         LEM_SYNC();      // V(1, T-1)
+        { half_m(I2{}); LPROF(lp_m); }                                               LEM_SYNC();      // M(2, T-1)
+        { half_v(I2{}); LPROF(lp_v); }                                               LEM_SYNC();      // V(2, T-1)
+    }
+    LPROF_FLUSH
+    // here: y_X(T) of the three tiles is published in yfr; role-B waves hold their y slices in st[]
+
+    if (a.with_mlp) {
+        const half8* ms = reinterpret_cast<const half8*>(a.mlp_s);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        w[gi][kt][s][pl] = ms[(size_t)(gi * 4 + kt) * 1024 + ((s * 4 + ks) * 2 + pl) * 64 + lane];
+        const float invA = a.scales[6], invB = a.scales[7];
+        // lemoutput_mlp: pass 0: role A takes tile 0, role B tile 1; pass 1: role A takes tile 2
+        for (int pass = 0; pass < 2; ++pass) {
+            const int X = pass ? 2 : role;
+            const bool work = pass == 0 || role == 0;
+            const half8* yb = yfr + X * LEM_WS_FR;
+            half8* hb = zfr + X * LEM_WS_FR;
+            if (work) {
+                f32x16 acc;
+                lem_ws_bias(bias_l + 512 + 32 * ks, hh, acc);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const half8 h0 = yb[((kt * 2 + s) * 2 + 0) * 64 + lane], l0 = yb[((kt * 2 + s) * 2 + 1) * 64 + lane];
+                        MSMP_MFMA_LOLO(2, acc, w[0][kt][s][1], l0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][kt][s][1], h0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][kt][s][0], l0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][kt][s][0], h0, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = swishf(acc[r] * invA);
+                lem_ws_publish(acc, hb, ks, lane);
+            }
+            __syncthreads();
+            if (work) {
+                f32x16 res;
+                lem_ws_bias(bias_l + 512 + H + 32 * ks, hh, res);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const half8 h0 = hb[((kt * 2 + s) * 2 + 0) * 64 + lane], l0 = hb[((kt * 2 + s) * 2 + 1) * 64 + lane];
+                        MSMP_MFMA_LOLO(2, res, w[1][kt][s][1], l0);
+                        res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][1], h0, res, 0, 0, 0);
+                        res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][0], l0, res, 0, 0, 0);
+                        res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][0], h0, res, 0, 0, 0);
+                    }
+                const long n = n0 + 32 * X + c;
+                if (n < a.n_nodes) {
+                    float* o = a.out + (size_t)n * H + 32 * ks + 4 * hh;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) v[m] = swishf(res[4 * q + m] * invB);
+                        *reinterpret_cast<f32x4*>(o + 8 * q) = v;
+                    }
+                }
+            }
+        }
+    } else if (role) {
+        // y itself: the role-B wave of slice ks holds its 32 channels of all three tiles
+#pragma unroll
+        for (int X = 0; X < 3; ++X) {
+            const long n = n0 + 32 * X + c;
+            if (n < a.n_nodes) {
+                float* o = a.out + (size_t)n * H + 32 * ks + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) v[m] = st[X][4 * q + m];
+                    *reinterpret_cast<f32x4*>(o + 8 * q) = v;
+                }
+            }
+        }
+    }
+}
+
 // fp32 chunks [128 out][32 k] (row-major, as `rec`) -> bf16x3 A fragments, acc order: thread = (chunk, s, T, lane)
 __global__ __launch_bounds__(256) void pack_lem_b3_kernel(const float* __restrict__ chunks, int n_chunks, float* __restrict__ out) {
     const int id = blockIdx.x * 256 + threadIdx.x;
@@ -1043,9 +1380,15 @@ __global__ __launch_bounds__(256) void pack_lem_b3_kernel(const float* __restric
 
 using namespace msmp;
 
+#if MSMP_PROF_LEM
+extern "C" __attribute__((visibility("default"))) int msmp_debug_prof_lem(unsigned long long* out16, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_lem), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof_lem), 16 * sizeof(unsigned long long));
+}
+#endif
 int g_lem_nodes = 1;     // msmp_tune("lem_nodes", 0): msmp_lem_encoder_nodes_f32 declines, callers assemble the [N,T,ninp] tensor (A/B)
-int g_lem_split = 3;     // 3: weight-stationary split kernel, 1: streamed-weight two-waves-per-SIMD split kernel, 2: one-wave split kernel,
-                         // 0: fp32 MFMA (msmp_tune "lem"; "split" 1/0 selects 3/0)
+int g_lem_split = 4;     // 4: weight-stationary anti-phased kernel (three node tiles), 3: weight-stationary two-tile kernel, 1: streamed-weight two-waves-per-SIMD split kernel, 2: one-wave split kernel,
+                         // 0: fp32 MFMA (msmp_tune "lem"; "split" 1/0 selects 4/0)
 extern "C" int64_t msmp_packed_lem_floats(void) { return lem_layout().total; }
 
 extern "C" int msmp_pack_lem_f32(const float* weights, const float* weights_lin_z, const float* bias, const float* bias_lin_z,
@@ -1076,7 +1419,22 @@ extern "C" int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len
               packed + L.mlpb, h_out};
     const unsigned grid = (unsigned)((n_nodes + 127) / 128);
     timing_begin(MSMP_K_LEM, (hipStream_t)stream);
-    if (g_lem_split == 3) {
+    if (g_lem_split == 4) {
+        LemWsArgs wa{xin, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s,
+                     packed + L.mlp_s, packed + L.bias_s, packed + L.wx_h, packed + L.mlpb_s, packed + L.scales, h_out};
+        const unsigned g96 = (unsigned)((n_nodes + 95) / 96);
+        hipStream_t st = (hipStream_t)stream;
+        switch (ninp) {
+            case 1: hipLaunchKernelGGL((lem_encoder_ws3_kernel<1, 0>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 2: hipLaunchKernelGGL((lem_encoder_ws3_kernel<2, 0>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 3: hipLaunchKernelGGL((lem_encoder_ws3_kernel<3, 0>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 4: hipLaunchKernelGGL((lem_encoder_ws3_kernel<4, 0>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 5: hipLaunchKernelGGL((lem_encoder_ws3_kernel<5, 0>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 6: hipLaunchKernelGGL((lem_encoder_ws3_kernel<6, 0>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 7: hipLaunchKernelGGL((lem_encoder_ws3_kernel<7, 0>), dim3(g96), dim3(512), 0, st, wa); break;
+            default: hipLaunchKernelGGL((lem_encoder_ws3_kernel<8, 0>), dim3(g96), dim3(512), 0, st, wa); break;
+        }
+    } else if (g_lem_split == 3) {
         LemWsArgs wa{xin, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s,
                      packed + L.mlp_s, packed + L.bias_s, packed + L.wx_h, packed + L.mlpb_s, packed + L.scales, h_out};
         const unsigned g64 = (unsigned)((n_nodes + 63) / 64);
@@ -1133,13 +1491,30 @@ extern "C" int msmp_lem_encoder_nodes_f32(const float* u, const float* pos_x, co
     MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31) && tw >= 1 && nv >= 1, MSMP_ERR_ARG, "msmp_lem_encoder_nodes_f32: bad sizes");
     const int ninp = (two_d ? 3 : 2) + nv;
     MSMP_REQUIRE(ninp <= LEM_MAX_INP, MSMP_ERR_UNSUPPORTED, "msmp_lem_encoder_nodes_f32: ninp=%d > %d", ninp, LEM_MAX_INP);
-    MSMP_REQUIRE(g_lem_split == 3 && g_lem_nodes, MSMP_ERR_UNSUPPORTED, "msmp_lem_encoder_nodes_f32: only the weight-stationary edition (msmp_tune lem 3)");
+    MSMP_REQUIRE((g_lem_split == 3 || g_lem_split == 4) && g_lem_nodes, MSMP_ERR_UNSUPPORTED,
+                 "msmp_lem_encoder_nodes_f32: only the weight-stationary editions (msmp_tune lem 3 / 4)");
     const LemLayout L = lem_layout();
     LemWsArgs wa{nullptr, u, pos_x, pos_t, vars, dt_cum, tw, nv, (long)n_nodes, tw, with_mlp, dt, packed + L.rec_s, packed + L.mlp_s,
                  packed + L.bias_s, packed + L.wx_h, packed + L.mlpb_s, packed + L.scales, h_out};
-    const unsigned g64 = (unsigned)((n_nodes + 63) / 64);
+    const unsigned g64 = (unsigned)((n_nodes + 63) / 64), g96 = (unsigned)((n_nodes + 95) / 96);
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_LEM, st);
+    if (g_lem_split == 4) {
+        if (!two_d) switch (ninp) {
+            case 3: hipLaunchKernelGGL((lem_encoder_ws3_kernel<3, 1>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 4: hipLaunchKernelGGL((lem_encoder_ws3_kernel<4, 1>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 5: hipLaunchKernelGGL((lem_encoder_ws3_kernel<5, 1>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 6: hipLaunchKernelGGL((lem_encoder_ws3_kernel<6, 1>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 7: hipLaunchKernelGGL((lem_encoder_ws3_kernel<7, 1>), dim3(g96), dim3(512), 0, st, wa); break;
+            default: hipLaunchKernelGGL((lem_encoder_ws3_kernel<8, 1>), dim3(g96), dim3(512), 0, st, wa); break;
+        } else switch (ninp) {
+            case 4: hipLaunchKernelGGL((lem_encoder_ws3_kernel<4, 2>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 5: hipLaunchKernelGGL((lem_encoder_ws3_kernel<5, 2>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 6: hipLaunchKernelGGL((lem_encoder_ws3_kernel<6, 2>), dim3(g96), dim3(512), 0, st, wa); break;
+            case 7: hipLaunchKernelGGL((lem_encoder_ws3_kernel<7, 2>), dim3(g96), dim3(512), 0, st, wa); break;
+            default: hipLaunchKernelGGL((lem_encoder_ws3_kernel<8, 2>), dim3(g96), dim3(512), 0, st, wa); break;
+        }
+    } else
     if (!two_d) switch (ninp) {
         case 3: hipLaunchKernelGGL((lem_encoder_ws_kernel<3, 1>), dim3(g64), dim3(512), 0, st, wa); break;
         case 4: hipLaunchKernelGGL((lem_encoder_ws_kernel<4, 1>), dim3(g64), dim3(512), 0, st, wa); break;

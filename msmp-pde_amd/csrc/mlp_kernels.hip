@@ -1350,7 +1350,7 @@ extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
     if (key && !strcmp(key, "lem")) { g_lem_split = value; return MSMP_OK; }
     if (key && !strcmp(key, "lem_nodes")) { g_lem_nodes = value; return MSMP_OK; }
-    if (key && !strcmp(key, "split")) { g_split = value; g_lem_split = value ? 3 : 0; return MSMP_OK; }
+    if (key && !strcmp(key, "split")) { g_split = value; g_lem_split = value ? 4 : 0; return MSMP_OK; }
     msmp::set_error("msmp_tune: unknown key");
     return MSMP_ERR_ARG;
 }

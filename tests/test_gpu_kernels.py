@@ -378,7 +378,8 @@ def test_graph_builders_random_grids(mp):
     assert np.array_equal(ei, O.knn_graph(x, 2, np.zeros(10, dtype=np.int64)))
 
 
-@pytest.mark.parametrize('ninp,t_len,n', [(4, 25, 300), (5, 25, 129), (6, 25, 64), (3, 7, 1000), (8, 50, 33), (1, 5, 70), (2, 3, 64), (7, 4, 200)])
+@pytest.mark.parametrize('ninp,t_len,n', [(4, 25, 300), (5, 25, 129), (6, 25, 64), (3, 7, 1000), (8, 50, 33), (1, 5, 70), (2, 3, 64), (7, 4, 200),
+                                          (1, 25, 500), (2, 25, 97), (4, 1, 96), (4, 2, 192)])
 def test_lem_encoder_kernel(mp, ninp, t_len, n):
     """Fused LEM encoder (recurrence + lemoutput_mlp) vs the float64 oracle cell.  PARITY UNPINNED against
     lem_cuda (absent from the reference); this pins the kernel to the restated cell only."""
@@ -390,7 +391,7 @@ def test_lem_encoder_kernel(mp, ninp, t_len, n):
         ys = lem.encode(xin, None)           # default: fp16-split matrix path, weight-stationary kernel
         hs = lem.encode(xin, mlp)
         older = {}
-        for variant in (1, 2):              # streamed-weight split kernels (two waves / one wave per SIMD)
+        for variant in (1, 2, 3):           # streamed-weight split kernels (two waves / one wave per SIMD), two-tile weight-stationary kernel
             mp.lib().msmp_tune(b'lem', variant)
             older[variant] = (lem.encode(xin, None), lem.encode(xin, mlp))
         mp.lib().msmp_tune(b'split', 0)
@@ -547,7 +548,7 @@ def test_lem_encoder_in_kernel_input_assembly(mp, two_d, nv, tw, n):
         try:
             assert lem.encode_nodes(u, pos_x, pos_t, variables, dt, two_d, mlp) is None      # only the default edition has it
         finally:
-            mp.lib().msmp_tune(b'lem', 3)
+            mp.lib().msmp_tune(b'lem', 4)
 
 
 def test_guard_bands_are_active(mp):
