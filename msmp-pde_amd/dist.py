@@ -40,19 +40,25 @@ def shard_graph(graph, rank, world):
     return out
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force_group=False):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun), one process per GPU.
-    Returns (rank, world, local_rank).  Single-process runs (WORLD_SIZE unset or 1) skip torch.distributed."""
+    Returns (rank, world, local_rank).  Single-process runs (WORLD_SIZE unset or 1) skip torch.distributed unless `force_group`
+    (or MSMP_FORCE_DIST=1 in the environment) asks for a ONE-rank group: every collective of the data-parallel path then really
+    goes through the backend (nccl = RCCL), which is how the RCCL code path is exercised on a single-GPU box."""
     import os
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    force_group = force_group or os.environ.get('MSMP_FORCE_DIST') == '1'
+    if (world > 1 or force_group) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(29400 + os.getpid() % 500))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

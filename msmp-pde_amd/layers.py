@@ -7,6 +7,7 @@ reference checkpoints load unchanged.  Parameters are created in float32 whateve
 is (the reference's import side effect makes it float64, temporal/solvers.py:10).
 """
 import ctypes
+import threading
 
 import torch
 from torch import nn
@@ -37,18 +38,19 @@ class _Workspace(object):
     in which the layers of the calling thread use buffers of their own instead (hipGraph capture: the captured launches must
     point at memory nobody replaces; solvers._GraphedForward keeps those buffers alive as long as the graph)."""
     _bufs = {}
-    _private = None
+    _tls = threading.local()      # `.private`: the calling THREAD's private buffer (a capture on one thread must not redirect another thread's forward)
 
     class _Private(object):
         def __init__(self, device):
             self.device, self.buf = device, None
 
         def __enter__(self):
-            self._outer, _Workspace._private = _Workspace._private, self
+            self._outer = getattr(_Workspace._tls, 'private', None)
+            _Workspace._tls.private = self
             return self
 
         def __exit__(self, *exc):
-            _Workspace._private = self._outer
+            _Workspace._tls.private = self._outer
 
         def buffers(self):
             return [self.buf]
@@ -59,7 +61,7 @@ class _Workspace(object):
 
     @classmethod
     def get(cls, nbytes, device):
-        p = cls._private
+        p = getattr(cls._tls, 'private', None)
         if p is not None and p.device == device:
             if p.buf is None or p.buf.numel() < nbytes:
                 assert not torch.cuda.is_current_stream_capturing() or p.buf is None, 'workspace grew during capture'

@@ -1,6 +1,6 @@
 """Fused AdamW on the HIP kernel msmp_adamw_f32 (the reference's optimizer is
 `optim.AdamW(model.parameters(), lr=args.lr)`, experiments/train.py:410).  A torch.optim.Optimizer subclass with the same
-constructor arguments, state layout (`step`, `exp_avg`, `exp_avg_sq`) and update rule as torch.optim.AdamW, so schedulers
+constructor arguments, state layout (one `step`, `exp_avg`, `exp_avg_sq` per parameter) and update rule as torch.optim.AdamW, so schedulers
 (train.py:411 MultiStepLR), state_dict() and the package's optimizer-step hook (packed-weight invalidation) work unchanged;
 every parameter tensor of the model is updated by one or two kernel launches."""
 import ctypes
@@ -24,27 +24,28 @@ class AdamW(torch.optim.Optimizer):
                 loss = closure()
         L = lib()
         for group in self.param_groups:
-            plan = group.get('_msmp_plan')
             live = [p for p in group['params'] if p.grad is not None]
-            if plan is None or plan['ids'] != [id(p) for p in live]:
-                plan = group['_msmp_plan'] = self._plan(live)
             if not live:
                 continue
             for p in live:
                 if p.grad.is_sparse or not p.grad.is_contiguous():
                     raise RuntimeError('msmp_pde_amd.optim.AdamW: dense contiguous gradients only')
-            plan['t'] += 1
-            plan['step'] += 1                                # ONE tensor object shared by the `step` entries of all these parameters
-            n = len(live)
-            grads = (ctypes.c_void_p * n)(*[p.grad.data_ptr() for p in live])     # zero_grad(set_to_none=True) re-allocates them
             b1, b2 = group['betas']
-            check(L.msmp_adamw_f32(n, plan['p'], grads, plan['m'], plan['v'], plan['numel'], float(group['lr']), float(b1), float(b2),
-                                   float(group['eps']), float(group['weight_decay']), plan['t'], current_stream()), 'msmp_adamw_f32')
+            # One launch per step count: parameters that received their first gradient later than their group peers (torch handles
+            # that) carry their own count, like everything else in torch's per-parameter state layout.
+            for t, plan in self._plans(group, live):
+                torch._foreach_add_(plan['steps'], 1)         # one `step` tensor PER parameter (torch.optim.AdamW's state layout)
+                n = len(plan['params'])
+                grads = (ctypes.c_void_p * n)(*[p.grad.data_ptr() for p in plan['params']])     # zero_grad(set_to_none=True) re-allocates them
+                check(L.msmp_adamw_f32(n, plan['p'], grads, plan['m'], plan['v'], plan['numel'], float(group['lr']), float(b1), float(b2),
+                                       float(group['eps']), float(group['weight_decay']), t + 1, current_stream()), 'msmp_adamw_f32')
+                plan['t'] = t + 1
         return loss
 
-    def _plan(self, live):
-        """Pointer tables of one parameter group (rebuilt only when the set of parameters with gradients changes)."""
-        t = None
+    def _plans(self, group, live):
+        """[(step count, pointer tables)] of a parameter group, one entry per distinct step count (normally one).  The tables are
+        cached and keyed on the STORAGES they point at (parameter, exp_avg, exp_avg_sq data pointers): model.to() / .float(),
+        `p.data = ...`, load_state_dict or a user-assigned state tensor rebuild them instead of leaving stale pointers."""
         for p in live:
             if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
                 raise RuntimeError('msmp_pde_amd.optim.AdamW: float32 contiguous CUDA parameters only')
@@ -53,18 +54,22 @@ class AdamW(torch.optim.Optimizer):
                 st['step'] = torch.zeros((), dtype=torch.float32)
                 st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            ti = int(st['step'].item())
-            if t is not None and ti != t:
-                raise RuntimeError('msmp_pde_amd.optim.AdamW: the parameters of a group must share their step count')
-            t = ti
-        n = len(live)
-        shared = torch.full((), float(t or 0), dtype=torch.float32)
-        for p in live:
-            self.state[p]['step'] = shared                   # torch's state layout keeps `step` per parameter: same value, one object
-        arr = lambda ts: (ctypes.c_void_p * n)(*[x.data_ptr() for x in ts])
-        return {'ids': [id(p) for p in live], 't': t or 0, 'step': shared, 'p': arr(live),
-                'm': arr([self.state[p]['exp_avg'] for p in live]), 'v': arr([self.state[p]['exp_avg_sq'] for p in live]),
-                'numel': (ctypes.c_int64 * n)(*[p.numel() for p in live])}
+        key = tuple((p.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr(), id(self.state[p]['step']))
+                    for p in live)
+        cache = group.get('_msmp_plan')
+        if cache is None or cache['key'] != key:
+            by_t = {}
+            for p in live:
+                by_t.setdefault(int(self.state[p]['step'].item()), []).append(p)       # host read-back: only when the tables are rebuilt
+            plans = []
+            for t, ps in sorted(by_t.items()):
+                n = len(ps)
+                arr = lambda ts: (ctypes.c_void_p * n)(*[x.data_ptr() for x in ts])
+                plans.append({'t': t, 'params': ps, 'steps': [self.state[p]['step'] for p in ps], 'p': arr(ps),
+                              'm': arr([self.state[p]['exp_avg'] for p in ps]), 'v': arr([self.state[p]['exp_avg_sq'] for p in ps]),
+                              'numel': (ctypes.c_int64 * n)(*[p.numel() for p in ps])})
+            cache = group['_msmp_plan'] = {'key': key, 'plans': plans}
+        return [(pl['t'], pl) for pl in cache['plans']]
 
     def state_dict(self):
         sd = super().state_dict()

@@ -194,6 +194,12 @@ class _SolverBase(nn.Module):
         ok = lambda t: t.is_cuda and t.dtype in (torch.float32, torch.float64)
         if not (ok(x) and ok(pos) and all(ok(c) for c, _ in cols)):
             return None
+        # the kernel indexes pos as [N, 2] = (t, x), every column as N contiguous values and x as [N, comps * time_window]:
+        # anything else takes the tensor expressions of the reference (which raise or broadcast as they always did)
+        comps = 2 if self.TWO_D else 1
+        if not (x.dim() == 2 and x.shape[1] == comps * self.time_window and pos.dim() == 2 and pos.shape == (x.shape[0], 2)
+                and all(c.numel() == x.shape[0] for c, _ in cols)):
+            return None
         x, pos = x.contiguous(), pos.contiguous()
         cs = [c.reshape(-1).contiguous() for c, _ in cols]
         n, tw_feat, nc = x.shape[0], x.shape[1], len(cs)
@@ -313,8 +319,63 @@ class _SolverBase(nn.Module):
                              "rescale the data or select the exact-fp32 kernels with lib().msmp_tune(b'split', 0)")
         return r
 
+    # >1: under no_grad, forward() evaluates the batch as that many sub-batches of WHOLE graphs, each on a stream of its own
+    # (graphs are independent: same values; bit-identical when a tile of the message kernel divides a graph).  The ~20 dependent
+    # kernels of a rollout step then form several chains whose kernels overlap: 1.06 -> 0.91 ms per step at 256 graphs,
+    # 6.56 -> 6.43 ms at 2048 (scripts/sub_batches.py).  Set on an instance (`model.sub_batches = 2`) or per class.
+    sub_batches = 1
+
     def forward(self, data):
         _lib.status_check()       # range sentinel of the fp16-split path: one host read, warns once per new flag (no device sync)
+        if self.sub_batches > 1 and not torch.is_grad_enabled() and data.x.is_cuda and not torch.cuda.is_current_stream_capturing():
+            return self._forward_sub_batches(data, int(self.sub_batches))
+        return self._forward(data)
+
+    def _sub_batch_plan(self, data, parts):
+        """Per-structure split of `data` into `parts` contiguous blocks of graphs (dist.shard_graph: node rows are views, edges
+        filtered and rebased), cached on the GraphStructure that travels with the graph through the rollout, with a stream each."""
+        from .dist import shard_graph
+        gs = structure_of(data)
+        plans = gs.__dict__.setdefault('_sub_batch_plans', {})
+        plan = plans.get(parts)
+        if plan is None:
+            n_parts = max(1, min(parts, gs.n_graphs))
+            subs = []
+            for r in range(n_parts):
+                sub = shard_graph(data, r, n_parts)
+                subs.append(sub)
+            # node offsets of the blocks
+            offs, o = [], 0
+            for sub in subs:
+                offs.append((o, o + sub.x.shape[0]))
+                o += sub.x.shape[0]
+            assert o == data.x.shape[0]
+            for sub in subs:
+                structure_of(sub).tiles()                   # CSR + tiles built once, on the calling stream
+            plan = plans[parts] = {'subs': subs, 'offs': offs, 'streams': [torch.cuda.Stream(device=data.x.device) for _ in subs]}
+        return plan
+
+    def _forward_sub_batches(self, data, parts):
+        plan = self._sub_batch_plan(data, parts)
+        n = data.x.shape[0]
+        cur = torch.cuda.current_stream()
+        out = None
+        per_node = [k for k, v in data.__dict__.items() if torch.is_tensor(v) and not k.startswith('_') and k not in ('edge_index', 'batch')
+                    and v.dim() >= 1 and v.shape[0] == n]
+        outs = []
+        for sub, (n0, n1), st in zip(plan['subs'], plan['offs'], plan['streams']):
+            for k in per_node:                                  # this step's node rows: views of the caller's tensors
+                setattr(sub, k, getattr(data, k)[n0:n1])
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(self._forward(sub))
+        for o, st in zip(outs, plan['streams']):
+            cur.wait_stream(st)
+            o.record_stream(cur)                                # allocated on the side stream, consumed on the caller's
+        out = torch.cat(outs, 0)
+        return out
+
+    def _forward(self, data):
         u_in = data.x
         pos = data.pos
         gs = structure_of(data)
@@ -333,7 +394,8 @@ class _SolverBase(nn.Module):
             feat = node_features(u, pos_x.reshape(-1).contiguous(), variables.contiguous()) if want_feat else None
         dkey = (tw, float(self.pde.dt), str(u.device))
         if getattr(self, '_dt_key', None) != dkey:       # cumsum(dt) of the Euler update: constant until pde.dt changes
-            self._dt_cum, self._dt_key = torch.cumsum(torch.ones(tw, dtype=torch.float32, device=u.device) * self.pde.dt, 0), dkey
+            with torch.inference_mode(False):      # a plain tensor: an inference-mode tensor could not enter the autograd decoder later
+                self._dt_cum, self._dt_key = torch.cumsum(torch.ones(tw, dtype=torch.float32, device=u.device) * self.pde.dt, 0), dkey
         dt = self._dt_cum
 
         h = self._encode(u, pos_x, pos_t, variables, dt)
@@ -416,11 +478,14 @@ class _GraphedForward:
     def _weight_state(self):
         """What the packed-weight caches key on: the global epoch (optimizer steps, invalidate_packed_weights) and every
         parameter's storage and version (load_state_dict, in-place edits)."""
-        return (PARAM_EPOCH[0], tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
+        pde = self.model.pde          # dt, L, tmax are baked into the captured kernel arguments (train.py:355-358 mutates them after construction)
+        return (PARAM_EPOCH[0], tuple((p.data_ptr(), p._version) for p in self.model.parameters()),
+                (float(pde.dt), float(pde.L), float(pde.tmax)))
 
     def _weight_blobs(self):
         return [getattr(m, attr) for m in self.model.modules() for attr in ('_packed', '_embed_blob') if getattr(m, attr, None) is not None]
 
+    @torch.no_grad()          # a re-capture from __call__ may come from a training loop: never capture the autograd path
     def _capture(self):
         from .layers import _Workspace
         model = self.model

@@ -12,13 +12,15 @@ import torch.distributed as dist
 
 
 def _world():
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    """Number of ranks; 0 when there is no process group at all (an initialised ONE-rank group still runs its collectives:
+    dist.init_from_env(force_group=True) exercises the RCCL path on a single GPU)."""
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 0
 
 
 def allreduce_gradients(params):
     """SUM-all-reduce the gradients of `params` as one flat buffer (a single collective per step)."""
     params = [p for p in params if p.grad is not None]
-    if _world() == 1 or not params:
+    if _world() == 0 or not params:
         return
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -35,7 +37,7 @@ def dp_loss_backward(model, graph):
     pred = model(graph)
     s_local = ((pred - graph.y.to(pred.dtype)) ** 2).sum()
     s_total = s_local.detach().clone()
-    if _world() > 1:
+    if _world() > 0:
         dist.all_reduce(s_total, op=dist.ReduceOp.SUM)
     loss = torch.sqrt(s_total)
     (s_local / (2.0 * loss)).backward()

@@ -1,0 +1,47 @@
+"""The 2048-graph rollout step as S sub-batches stepping concurrently on S streams (eager launches, per-stream workspaces):
+does overlapping kernels of different sub-batches (tails of one kernel's grid beside the head of the next) pay?
+    python scripts/sub_batches.py [graphs]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+import msmp_pde_amd as mp
+args = bench.parse(['--no-cpu-baseline', '--no-extras'])
+n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+dev = torch.device('cuda:0')
+
+def timed(fn, n):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+with torch.no_grad():
+    whole = bench.Workload(args, mp, dev, n_graphs, seed=1)
+    whole.first()
+    timed(whole.step, 150)                     # pre-heat
+    res = {1: timed(whole.step, 60)}
+    for S in (2, 3, 4):
+        parts = [bench.Workload(args, mp, dev, n_graphs // S, seed=10 * S + i) for i in range(S)]
+        streams = [torch.cuda.Stream() for _ in range(S)]
+        for p, s in zip(parts, streams):
+            p.model = whole.model
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                p.first()
+        def step():
+            for p, s in zip(parts, streams):
+                with torch.cuda.stream(s):
+                    p.step()
+        timed(step, 20)
+        res[S] = timed(step, 60)
+        res[-S] = timed(lambda: [p.step() for p in parts], 30)       # the same sub-batches one after the other on one stream
+    t1 = timed(whole.step, 60)
+with torch.no_grad():
+    whole.model.sub_batches = 2
+    timed(whole.step, 10)
+    t_mode = timed(whole.step, 60)
+    whole.model.sub_batches = 1
+print(f'{n_graphs} graphs: Solver.sub_batches = 2 (the product mode, one Workload): {t_mode:.3f} ms per step')
+print(f'{n_graphs} graphs, ms per rollout step: one batch {res[1]:.3f} (again at the end: {t1:.3f}); '
+      + '; '.join(f'{S} sub-batches on {S} streams {res[S]:.3f} (one stream: {res[-S]:.3f})' for S in (2, 3, 4)))

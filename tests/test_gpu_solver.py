@@ -522,6 +522,34 @@ def test_range_sentinel_in_plain_forward(mp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name,exp,parts', [('MSMP-PDE', 'E2', 2), ('MSMP-PDE', 'E2', 3), ('MSMP-PDE2D', 'RPU', 2), ('MP-PDE', 'WE3', 4)])
+def test_sub_batches_on_streams_match_the_whole_batch(mp, name, exp, parts):
+    """Solver.sub_batches: the batch evaluated as `parts` blocks of whole graphs, each on a stream of its own,
+    gives the rows of the one-batch evaluation -- bit for bit where a message-kernel tile divides a graph (E2), within fp32
+    rounding otherwise (another alignment of a target's messages in the wave's MFMA sum) -- over a few rollout steps, uneven
+    splits included (7 graphs in 2, 3, 4 parts), and leaves no work behind on the side streams."""
+    torch.manual_seed(2)
+    case = synthetic_case(mp, exp, bsz=7, seed=4)
+    model = mp.MODEL_NAMES[name](case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=2).cuda().eval()
+    data = case.graph.to('cuda')
+    gc = case.creator
+    with torch.no_grad():
+        for it in range(3):
+            model.sub_batches = 1
+            ref = model(data)
+            model.sub_batches = parts
+            out = model(data)
+            if exp == 'E2':
+                assert torch.equal(out, ref), it
+            else:
+                assert (out - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), it
+            same = [50 + TW * (it + 1)] * 7
+            _, labels = gc.create_data(case.u_super, same)
+            data = gc.create_next_graph(data, ref, labels, same)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 def test_forwards_on_two_streams_do_not_share_scratch(mp):
     """Two batches evaluated concurrently on two streams of one device (what an overlapped rollout of sub-batches does) give the bits of
     the one-after-the-other evaluation: the layers' scratch workspace is per (device, stream)."""

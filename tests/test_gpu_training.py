@@ -113,6 +113,48 @@ def test_data_parallel_gradients_are_exact(mp, tmp_path):
         assert err < 1e-4 * ref.abs().max().item() + 1e-5 * scale, (k, err, ref.abs().max().item(), scale)
 
 
+def _rccl_worker(port, out_path):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import msmp_pde_amd as mp_
+    from msmp_pde_amd import dist as D, train as T
+    D.init_from_env(backend='nccl', force_group=True)       # a ONE-rank RCCL group: the collectives below really run on the backend
+    assert torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl' and T._world() == 1
+    ranks_seen = int(round(D.reduce_scalar(1, 'sum')))      # bench.py's rank count, an all-reduce on the GPU
+    torch.manual_seed(5)
+    case = synthetic_case(mp_, 'E2', bsz=4, seed=6)
+    model = mp_.MP_PDE_SolverGated(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=2).cuda()
+    loss = T.dp_loss_backward(model, case.graph.to('cuda'))
+    D.barrier()
+    torch.save({'loss': loss.item(), 'ranks_seen': ranks_seen, 'grads': {k: p.grad.cpu() for k, p in model.named_parameters()}}, out_path)
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_path_runs_on_one_gpu(mp, tmp_path):
+    """`backend='nccl'` (RCCL) executed for real -- a one-rank group on the box's single GPU runs bench.py's
+    rank count and training's two all-reduces (the scalar S and the flat gradient buffer); the gradients are those of the
+    ungrouped run, bit for bit (a one-rank SUM all-reduce is the identity).  In a child process: a process group per test
+    process would otherwise outlive the test."""
+    import torch.multiprocessing as tmp
+    from msmp_pde_amd import train as T
+    out_path = str(tmp_path / 'rccl.pt')
+    ctx = tmp.get_context('spawn')
+    p = ctx.Process(target=_rccl_worker, args=(29900 + (os.getpid() % 90), out_path))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    got = torch.load(out_path, weights_only=True)
+    assert got['ranks_seen'] == 1
+    torch.manual_seed(5)
+    case = synthetic_case(mp, 'E2', bsz=4, seed=6)
+    model = mp.MP_PDE_SolverGated(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=2).cuda()
+    loss = T.dp_loss_backward(model, case.graph.to('cuda'))         # no process group here
+    assert loss.item() == got['loss']
+    for k, p_ in model.named_parameters():
+        assert torch.equal(p_.grad.cpu(), got['grads'][k]), k
+
+
 def test_training_step_runs_and_decreases_loss(mp):
     """training_step (pushforward unrolling + AdamW) on the HIP path: the loss on a fixed batch goes down."""
     from msmp_pde_amd import train as T
@@ -463,3 +505,31 @@ def test_fused_adamw_matches_torch(mp):
             assert err <= 2e-7 * max(1.0, pb.abs().max().item()) + 1e-9, (it, name, err)
     st = oa.state_dict()
     assert set(st['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+    # torch's state layout for real: one `step` tensor per parameter, so that a state_dict round trip through
+    # torch.save / torch.load into torch.optim.AdamW resumes with step + 1 per step (a shared tensor advanced it by the number of
+    # parameters), and the continued trajectories of the two optimizers agree
+    import io
+    assert len({id(oa.state[p]['step']) for p in a.parameters()}) == len(list(a.parameters()))
+    buf = io.BytesIO()
+    torch.save(oa.state_dict(), buf)
+    buf.seek(0)
+    oc = torch.optim.AdamW(a.parameters(), lr=1e-3)
+    oc.load_state_dict(torch.load(buf, weights_only=True))
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        g = torch.randn(pa.shape, device='cuda', generator=gen)
+        pa.grad, pb.grad = g.clone(), g.clone()
+    oc.step(); ob.step()
+    assert all(float(oc.state[p]['step']) == 5.0 for p in a.parameters())
+    for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
+        err = (pa - pb).abs().max().item()
+        assert err <= 4e-7 * max(1.0, pb.abs().max().item()) + 1e-9, (name, err)
+    # a parameter that gets its first gradient later than its group peers, and a storage that was replaced (p.data = ...): handled
+    w = [torch.nn.Parameter(torch.randn(5, 3, device='cuda')) for _ in range(2)]
+    od = mp.optim.AdamW(w, lr=1e-2)
+    w[0].grad = torch.ones_like(w[0])
+    od.step()
+    w[1].grad = torch.ones_like(w[1])
+    w[0].data = w[0].data.clone()
+    od.step()
+    torch.cuda.synchronize()
+    assert float(od.state[w[0]]['step']) == 2.0 and float(od.state[w[1]]['step']) == 1.0

@@ -227,6 +227,21 @@ def test_bench_launcher_starts_one_rank_per_gpu():
     assert r2.returncode != 0 and 'WORLD_SIZE=1' in r2.stderr
 
 
+def test_bench_launcher_stops_the_other_ranks_when_one_fails():
+    """a rank that dies leaves the others inside a collective until the backend's timeout.  The launcher polls
+    its children: rank 1 exits with code 3 before joining the group, rank 0 (blocked in the rendezvous) is terminated, the
+    launcher returns 3 within seconds and replays the failing rank's stderr."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo', '--launcher-selftest',
+                        '--selftest-fail-rank', '1'], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    assert time.time() - t0 < 120
+    assert 'rank 1 exited with code 3' in r.stderr and '[rank 1] selftest: this rank fails on purpose' in r.stderr
+
+
 def test_decoder_convolution_as_toeplitz_gemm_matches_conv1d():
     """solvers._conv1d_as_matmul (the AUTOGRAD decoder: Conv1d as one dense GEMM against the convolution's Toeplitz matrix, itself the
     weight times a fixed shift tensor) against torch.nn.functional.conv1d, forward and all three gradients, for every decoder geometry
