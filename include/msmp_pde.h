@@ -438,6 +438,26 @@ int msmp_pack_mlp2_f32(const float* w1, const float* b1, const float* w2, const 
 int msmp_mlp2_swish_f32(const float* x, int64_t n_nodes, int k_in, const float* packed, float* out, msmp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Width-generic layer pieces: the GLU classes (hidden width 164; experiments/models_gnn.py:1379-1523 MP_PDE_SolverLEMLinGatedGLU,
+ * models_gnn2D.py:1198-1366 MP_PDE_Solver2DLEMLinGatedGLU; train.py names 'MSGMP-PDE', 'MSGMP-PDE2D').  The same GNN_LayerLin
+ * (message :132-138, mean :107, update :140-149, InstanceNorm :129, gated blend :1486-1489) evaluated from HBM-bound kernels around
+ * a general fp32-exact row GEMM; tensors are row-major with row stride ld (a multiple of 4, >= width; padding columns stay 0).
+ * ------------------------------------------------------------------------------------------- */
+/* out[rows, 0 : 128 ceil(n_out / 128)] = f(x[rows, 0:k] w[n_out, k]^T + bias): mode 0 identity, 1 Swish, 2 out += x w^T (no bias). */
+size_t msmp_linear_workspace_bytes(int k, int n_out);
+int msmp_linear_f32(const float* x, int ldx, int64_t rows, int k, const float* w, int ldw, const float* bias, int n_out, int mode,
+                    float* out, int ld_out, void* workspace, size_t workspace_bytes, msmp_stream_t stream);
+/* out[e] = Swish(p[tgt[e]] + q[col[e]])  (message_net_1 factorised per node, then its Swish) */
+int msmp_wide_gather_swish_f32(const float* p, const float* q, const int32_t* tgt, const int32_t* col, int64_t n_edges, int width, int ld,
+                               float* out, msmp_stream_t stream);
+/* PyG aggr='mean' over CSR rows, any width */
+int msmp_wide_scatter_mean_f32(const float* msg, const int32_t* rowptr, int64_t n_nodes, int width, int ld, float* agg_out, msmp_stream_t stream);
+int msmp_wide_swish_f32(const float* x, int64_t n_floats, float* out, msmp_stream_t stream);
+/* gate_pre == NULL: out = InstanceNorm(main_pre); else out = (1 - tau) h + tau Swish(IN(main_pre)), tau = sigmoid(IN(gate_pre)) */
+int msmp_wide_norm_blend_f32(const float* h, const float* gate_pre, const float* main_pre, const int32_t* graph_ptr, int64_t n_graphs,
+                             int width, int ld, float eps, float* out, msmp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * In-library kernel timing (measurement aid for bench.py; off by default, not part of the data path)
  * When enabled, every launch of the named kernel family is bracketed by hipEvents recorded on the
  * launch stream.  msmp_timing_read synchronises on the recorded events and returns the number of

@@ -13,5 +13,5 @@ from . import optim                                                             
 from .solvers import (MP_PDE_Solver, MP_PDE_SolverGated, MP_PDE_SolverLEMLinGated, MP_PDE_Solver2D,   # noqa: F401
                       MP_PDE_Solver2DGated, MP_PDE_Solver2DLEMLinGated, MP_PDE_SolverLEMLin, MP_PDE_Solver2DLEMLin,
                       MP_PDE_Solver2DLEMLinG2, MSSMP_PDE_Solver, MSSMP_PDE_Solver_sub,
-                      MP_PDE_SolverLEMLinGatedSave, MP_PDE_SolverLSTMLin, MP_PDE_SolverLSTMLinGated, MP_PDE_Solver2DLSTMLin, MP_PDE_Solver2DLSTMLinGated,
+                      MP_PDE_SolverLEMLinGatedSave, MP_PDE_SolverLEMLinGatedGLU, MP_PDE_Solver2DLEMLinGatedGLU, MP_PDE_SolverLSTMLin, MP_PDE_SolverLSTMLinGated, MP_PDE_Solver2DLSTMLin, MP_PDE_Solver2DLSTMLinGated,
                       MODEL_NAMES)

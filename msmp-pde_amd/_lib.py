@@ -86,6 +86,12 @@ SIGNATURES = {
     'msmp_mlp2_swish_f32': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'msmp_linear_swish_workspace_bytes': (c_size_t, [c_int, c_int]),
     'msmp_linear_swish_f32': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'msmp_linear_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'msmp_linear_f32': (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'msmp_wide_gather_swish_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    'msmp_wide_scatter_mean_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    'msmp_wide_swish_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    'msmp_wide_norm_blend_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p]),
     'msmp_timing_enable': (c_int, [c_int]),
     'msmp_timing_reset': (c_int, []),
     'msmp_timing_read': (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),

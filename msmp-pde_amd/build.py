@@ -24,6 +24,7 @@ SOURCES = {  # file -> extra flags
     'lem_train_kernel.hip': [],
     'train_kernels.hip': [],
     'mlp2_kernel.hip': [],
+    'wide_kernels.hip': [],
     'decoder_kernel.hip': [],
     'graph_kernels.hip': ['-ffp-contract=off'],   # float64 distance compares must round like the host's
 }

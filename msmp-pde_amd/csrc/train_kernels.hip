@@ -718,7 +718,7 @@ constexpr int RG_CHUNK_FLOATS = RG_CHUNK_U4 * 4;       // 24 KB
 struct RgPackJob {
     const float* w;      // row-major, row stride ldw
     u32x4* out;          // n_chunks * RG_CHUNK_U4 fragments
-    int ldw, K, n_chunks, col0, transposed;
+    int ldw, K, n_chunks, col0, transposed, n_rows;     // rows (output channels) >= n_rows read as zero (forward form; msmp_linear_f32's last group)
     // transposed = 0: W_eff[o][k] = w[(col0 + o) * ldw + k]   (forward form: rows of w are output channels)
     // transposed = 1: W_eff[o][k] = w[k * ldw + col0 + o]     (data-gradient form: the reduction runs over w's rows)
     int first_block;
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void rg_pack_kernel(RgPackArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int k = k0 + i;
-        v[i] = k < j.K ? (j.transposed ? j.w[(size_t)k * j.ldw + j.col0 + o] : j.w[(size_t)(j.col0 + o) * j.ldw + k]) : 0.f;
+        v[i] = (k < j.K && (j.transposed || j.col0 + o < j.n_rows)) ? (j.transposed ? j.w[(size_t)k * j.ldw + j.col0 + o] : j.w[(size_t)(j.col0 + o) * j.ldw + k]) : 0.f;
     }
     const Bf3 f = split_bf16x3(v);
     u32x4* dst = j.out + (size_t)(((chunk * 2 + s) * 4 + T) * 3) * 64 + lane;
@@ -897,6 +897,7 @@ static void carve_frags(u32x4*& p, int kmsg, int kupd, HeadFrags& f) {
 static void add_pack(RgPackArgs& a, int& blocks, const float* w, int ldw, int K, int col0, int transposed, u32x4* out) {
     RgPackJob& j = a.job[a.n_jobs++];
     j.w = w; j.out = out; j.ldw = ldw; j.K = K; j.n_chunks = (K + 31) / 32; j.col0 = col0; j.transposed = transposed; j.first_block = blocks;
+    j.n_rows = 0x7fffffff;
     blocks += (j.n_chunks * 512 + 255) / 256;
 }
 static int pack_head_frags(const float* const* p, int kmsg, int kupd, const HeadFrags& f, RgPackArgs& a, int& blocks, const float* wp, const float* wq,
@@ -1074,6 +1075,51 @@ extern "C" int msmp_linear_swish_f32(const float* x, int64_t rows, int k, const 
     RC(check_launch("rg_pack_kernel"));
     for (int g = 0; g < groups; ++g)
         RC(rows_gemm(4, x, k, (long)rows, k, fp + (size_t)g * chunks * RG_CHUNK_U4, bias + 128 * g, nullptr, out + 128 * g, n_out, nullptr, st));
+    return MSMP_OK;
+}
+
+// General row GEMM of the width-generic layer path (the GLU classes, hidden width 164: experiments/models_gnn.py:1379-1523,
+// models_gnn2D.py:1198-1366):  out[rows, 0:128 g] = f(x[rows, 0:k] w[n_out, k]^T + bias)  in 128-column groups on the fp32-exact bf16x3
+// row-GEMM kernel above; columns n_out .. 128 ceil(n_out / 128) - 1 of `out` are written too (as f(0 + 0)): ld_out must cover them.
+//   mode 0: acc + bias    1: Swish(acc + bias)    2: out += acc (bias ignored)
+extern "C" size_t msmp_linear_workspace_bytes(int k, int n_out) {
+    if (k < 1 || k > 1024 || n_out < 1 || n_out > 128 * (RG_MAX_PACK / 2)) return 0;
+    const int groups = (n_out + 127) / 128;
+    return (size_t)groups * ((k + 31) / 32) * RG_CHUNK_U4 * sizeof(u32x4) + (size_t)groups * 128 * sizeof(float) + 512;
+}
+__global__ void linear_pad_bias_kernel(const float* __restrict__ bias, int n_out, int n_pad, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_pad) out[i] = (bias && i < n_out) ? bias[i] : 0.f;
+}
+extern "C" int msmp_linear_f32(const float* x, int ldx, int64_t rows, int k, const float* w, int ldw, const float* bias, int n_out, int mode,
+                               float* out, int ld_out, void* workspace, size_t workspace_bytes, msmp_stream_t stream) {
+    MSMP_REQUIRE(x && w && out && workspace, MSMP_ERR_ARG, "msmp_linear_f32: null pointer");
+    MSMP_REQUIRE(mode >= 0 && mode <= 2, MSMP_ERR_ARG, "msmp_linear_f32: mode %d", mode);
+    const size_t need = msmp_linear_workspace_bytes(k, n_out);
+    MSMP_REQUIRE(need, MSMP_ERR_UNSUPPORTED, "msmp_linear_f32: k = %d (1..1024), n_out = %d (1..%d)", k, n_out, 128 * (RG_MAX_PACK / 2));
+    const int groups = (n_out + 127) / 128, chunks = (k + 31) / 32;
+    MSMP_REQUIRE(rows > 0 && rows < (1L << 31) && ldx >= k && ldx % 4 == 0 && ldw >= k && ld_out >= 128 * groups && ld_out % 4 == 0 &&
+                 ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, MSMP_ERR_ARG,
+                 "msmp_linear_f32: bad sizes (ldx, ld_out multiples of 4, 16-byte aligned rows, ld_out >= %d)", 128 * groups);
+    MSMP_REQUIRE(workspace_bytes >= need, MSMP_ERR_WORKSPACE, "msmp_linear_f32: workspace %zu < %zu", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    u32x4* fp = reinterpret_cast<u32x4*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float* bpad = reinterpret_cast<float*>(fp + (size_t)groups * chunks * RG_CHUNK_U4);
+    RgPackArgs pa;
+    pa.n_jobs = 0;
+    int blocks = 0;
+    for (int g = 0; g < groups; ++g) {
+        add_pack(pa, blocks, w, ldw, k, 128 * g, 0, fp + (size_t)g * chunks * RG_CHUNK_U4);
+        pa.job[pa.n_jobs - 1].n_rows = n_out;
+    }
+    for (int i = pa.n_jobs; i < RG_MAX_PACK; ++i) pa.job[i] = pa.job[0];
+    hipLaunchKernelGGL(rg_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pa);
+    RC(check_launch("rg_pack_kernel"));
+    hipLaunchKernelGGL(linear_pad_bias_kernel, dim3((unsigned)((128 * groups + 255) / 256)), dim3(256), 0, st, mode == 2 ? nullptr : bias, n_out, 128 * groups, bpad);
+    RC(check_launch("linear_pad_bias_kernel"));
+    const int epi = mode == 0 ? 1 : (mode == 1 ? 4 : 5);
+    for (int g = 0; g < groups; ++g)
+        RC(rows_gemm(epi, x, ldx, (long)rows, k, fp + (size_t)g * chunks * RG_CHUNK_U4, bpad + 128 * g, nullptr, out + 128 * g, ld_out, nullptr, st));
     return MSMP_OK;
 }
 

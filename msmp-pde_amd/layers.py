@@ -80,8 +80,11 @@ class _MPLayerBase(nn.Module):
 
     def __init__(self, in_features, out_features, hidden_features, time_window, n_variables):
         super().__init__()
-        if not (in_features == out_features == hidden_features == HIDDEN):
-            raise ValueError(f'the HIP kernels are built for hidden width {HIDDEN}')
+        if not (in_features == out_features == hidden_features):
+            raise ValueError('in_features, hidden_features and out_features must be equal (they are in every class of the reference)')
+        # hidden width 128: the fused kernels.  Any other width (the GLU classes: 164): the width-generic layer of wide_kernels.hip
+        # around msmp_linear_f32 (same formulas, HBM-bound pieces; `mp_layer` dispatches on this flag)
+        self.wide = hidden_features != HIDDEN
         if not 1 <= n_variables <= _lib.MSMP_MAX_VARS:
             raise ValueError(f'n_variables must be in 1..{_lib.MSMP_MAX_VARS}')
         self.in_features, self.out_features, self.hidden_features = in_features, out_features, hidden_features
@@ -104,6 +107,8 @@ class _MPLayerBase(nn.Module):
 
     def packed(self):
         """Kernel-layout weight blob (msmp_pack_layer_f32), re-packed only when a parameter changed."""
+        if self.wide:
+            raise _lib.MsmpError(f'the packed layer blob exists for hidden width {HIDDEN} only')
         ps = self._params8()
         key = (_lib.PARAM_EPOCH[0], ps[0].data_ptr(), ps[7].data_ptr(), ps[0].dtype) + tuple(p._version for p in ps)
         if key != self._packed_key:
@@ -117,6 +122,21 @@ class _MPLayerBase(nn.Module):
             check(L.msmp_pack_layer_f32(*[ptr(t) for t in f], self.time_window, self.n_variables, ptr(blob),
                                         current_stream()), 'msmp_pack_layer_f32')
             self._packed, self._packed_key = blob, key
+        return self._packed
+
+    def wide_weights(self):
+        """The wide path's operands, cached per parameter version: message_net_1 factorised per node (models_gnn.py:132-138):
+        P = Wp [h | u | pos | vars] + b1 for the edge's target, Q = Wq [h | u | pos | vars] for its source, with
+        Wp = [W1[:, :W] | W1[:, 2W:]], Wq = [W1[:, W:2W] | -W1[:, 2W:2W+tw+1] | 0]."""
+        ps = self._params8()
+        key = (_lib.PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in ps)
+        if key != self._packed_key:
+            w1 = ps[0].detach().to(torch.float32)
+            W, tw = self.hidden_features, self.time_window
+            wp = torch.cat((w1[:, :W], w1[:, 2 * W:]), 1).contiguous()
+            wq = torch.cat((w1[:, W:2 * W], -w1[:, 2 * W:2 * W + tw + 1], torch.zeros_like(w1[:, 2 * W + tw + 1:])), 1).contiguous()
+            self._packed = (wp, wq) + tuple(p.detach().to(torch.float32).contiguous() for p in ps[1:])
+            self._packed_key = key
         return self._packed
 
     def forward(self, x, u, pos, variables, edge_index, batch, structure=None):
@@ -181,6 +201,96 @@ def _mp_layer_hip(h, u, pos_x, variables, gs, main, gate, eps, dense_message=Non
     return out
 
 
+def _wide_linear(x, k, w, bias, n_out, mode, out, ws):
+    L = lib()
+    check(L.msmp_linear_f32(ptr(x), x.shape[1], x.shape[0], k, ptr(w), w.shape[1], ptr(bias), n_out, mode, ptr(out), out.shape[1],
+                            ptr(ws), ws.numel(), current_stream()), 'msmp_linear_f32')
+
+
+def _wide_head(h, feat_cat, k_feat, variables, gs, layer, ld, ws):
+    """One GNN_LayerLin head at hidden width W != 128 up to its pre-norm output [N, ld] (experiments/models_gnn.py:124-149)."""
+    L = lib()
+    n, W, e = h.shape[0], layer.hidden_features, gs.n_edges
+    wp, wq, b1, w2, b2, w3, b3, w4, b4 = layer.wide_weights()
+    dev = h.device
+    P = torch.empty(n, ld, dtype=torch.float32, device=dev)
+    Q = torch.empty(n, ld, dtype=torch.float32, device=dev)
+    _wide_linear(feat_cat, k_feat, wp, b1, W, 0, P, ws)
+    _wide_linear(feat_cat, k_feat, wq, None, W, 0, Q, ws)
+    a1 = torch.empty(max(e, 1), ld, dtype=torch.float32, device=dev)
+    check(L.msmp_wide_gather_swish_f32(ptr(P), ptr(Q), ptr(gs.tgt), ptr(gs.col), e, W, ld, ptr(a1), current_stream()), 'msmp_wide_gather_swish_f32')
+    msg = torch.empty(max(e, 1), ld, dtype=torch.float32, device=dev)
+    if e:
+        _wide_linear(a1[:e], W, w2, b2, W, 1, msg[:e], ws)
+    agg = torch.empty(n, ld, dtype=torch.float32, device=dev)
+    check(L.msmp_wide_scatter_mean_f32(ptr(msg), ptr(gs.rowptr), n, W, ld, ptr(agg), current_stream()), 'msmp_wide_scatter_mean_f32')
+    upd_in = torch.cat((h[:, :W], agg[:, :W], variables), 1)
+    pad = (-upd_in.shape[1]) % 4
+    if pad:
+        upd_in = torch.nn.functional.pad(upd_in, (0, pad))
+    upd_in = upd_in.contiguous()
+    z = torch.empty(n, ld, dtype=torch.float32, device=dev)
+    _wide_linear(upd_in, 2 * W + variables.shape[1], w3, b3, W, 1, z, ws)
+    y = torch.empty(n, ld, dtype=torch.float32, device=dev)
+    _wide_linear(z, W, w4, b4, W, 0, y, ws)
+    return y
+
+
+def _mp_layer_wide(h, u, pos_x, variables, gs, main, gate, eps):
+    """GNN_LayerLin (or a gated pair of them) at a hidden width other than 128: the HIP path of wide_kernels.hip.  h [N, W]."""
+    L = lib()
+    W = main.hidden_features
+    if main.MODE != _lib.MSMP_LAYER_LIN:
+        raise _lib.MsmpError('the width-generic layer path implements GNN_LayerLin (the layer of the GLU classes)')
+    ld = 128 * ((W + 127) // 128)
+    n = h.shape[0]
+    hp = torch.zeros(n, ld, dtype=torch.float32, device=h.device)
+    hp[:, :W] = h
+    feat_cat = torch.cat((h, u, pos_x.reshape(-1, 1), variables), 1)
+    k_feat = feat_cat.shape[1]
+    pad = (-feat_cat.shape[1]) % 4
+    if pad:
+        feat_cat = torch.nn.functional.pad(feat_cat, (0, pad))
+    feat_cat = feat_cat.contiguous()
+    k_max = max(feat_cat.shape[1], 2 * W + variables.shape[1] + 3)
+    ws = _Workspace.get(L.msmp_linear_workspace_bytes(k_max, W), h.device)
+    y_main = _wide_head(hp, feat_cat, k_feat, variables, gs, main, ld, ws)
+    y_gate = _wide_head(hp, feat_cat, k_feat, variables, gs, gate, ld, ws) if gate is not None else None
+    out = torch.empty(n, ld, dtype=torch.float32, device=h.device)
+    check(L.msmp_wide_norm_blend_f32(ptr(hp), ptr(y_gate), ptr(y_main), ptr(gs.graph_ptr), gs.n_graphs, W, ld, eps, ptr(out), current_stream()),
+          'msmp_wide_norm_blend_f32')
+    return out[:, :W].contiguous()
+
+
+def _mp_layer_wide_autograd(h, u, pos_x, variables, gs, main, gate, eps):
+    """The same layer as differentiable PyTorch-ROCm ops (training of the GLU ablation classes): gathers, F.linear, index_add_
+    mean, InstanceNorm and the blend, formula by formula as experiments/models_gnn.py:124-149, 1486-1489."""
+    import torch.nn.functional as F
+    i, j = gs.tgt_long, gs.col_long
+    n = h.shape[0]
+    deg = (gs.rowptr[1:] - gs.rowptr[:-1]).clamp(min=1).to(h.dtype)[:, None]
+    batch = torch.repeat_interleave(torch.arange(gs.n_graphs, device=h.device), (gs.graph_ptr[1:] - gs.graph_ptr[:-1]).long())
+    cnt = (gs.graph_ptr[1:] - gs.graph_ptr[:-1]).clamp(min=1).to(h.dtype)[:, None]
+    pos = pos_x.reshape(-1, 1)
+
+    def head(layer):
+        sw = lambda x: x * torch.sigmoid(x)
+        cat = torch.cat((h[i], h[j], u[i] - u[j], pos[i] - pos[j], variables[i]), -1)
+        m = sw(layer.message_net_2[0](sw(layer.message_net_1[0](cat))))
+        agg = torch.zeros(n, m.shape[1], dtype=m.dtype, device=m.device).index_add_(0, i, m) / deg
+        y = layer.update_net_2[0](sw(layer.update_net_1[0](torch.cat((h, agg, variables), -1))))
+        mean = torch.zeros(gs.n_graphs, y.shape[1], dtype=y.dtype, device=y.device).index_add_(0, batch, y) / cnt
+        yc = y - mean[batch]
+        var = torch.zeros_like(mean).index_add_(0, batch, yc * yc) / cnt
+        return yc / torch.sqrt(var + eps)[batch]
+
+    out = head(main)
+    if gate is None:
+        return out
+    tau = torch.sigmoid(head(gate))
+    return (1.0 - tau) * h + tau * (out * torch.sigmoid(out))
+
+
 def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense_message=None, feat=None):
     """One message-passing layer (or one gated pair) on the device through msmp_mp_layer_f32.
     h [N,128], u [N,Tw], pos_x [N,1] or [N], variables [N,nv]: float32 CUDA tensors.
@@ -191,6 +301,10 @@ def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense
     if gs is None or h.device.type != 'cuda':
         raise _lib.MsmpError('mp_layer needs CUDA tensors and a GraphStructure (HIP path only, no CPU fallback)')
     need_grad = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in main._params8()))
+    if main.wide:
+        if need_grad:
+            return _mp_layer_wide_autograd(h, u.to(h.dtype), pos_x, variables.to(h.dtype), gs, main, gate, eps)
+        return _mp_layer_wide(_f32c(h), _f32c(u), _f32c(pos_x).reshape(-1), _f32c(variables), gs, main, gate, eps)
     hd, u, pos_x, variables = _f32c(h), _f32c(u), _f32c(pos_x).reshape(-1), _f32c(variables)
     n = hd.shape[0]
     assert n == gs.n_nodes and hd.shape[1] == HIDDEN and u.shape[1] == main.time_window

@@ -141,8 +141,10 @@ class LEM(nn.Module):
 
     def forward_nodes(self, xin):
         """Same with node-major step inputs xin [N, T, ninp] (the layout the kernels read)."""
-        if not xin.is_cuda or self.nhid != 128:
-            raise RuntimeError('LEM runs on the HIP kernels only (CUDA tensors, 128 hidden features); there is no CPU fallback')
+        if not xin.is_cuda:
+            raise RuntimeError('LEM needs CUDA tensors; there is no CPU fallback')
+        if self.nhid != 128:            # the GLU classes (164 hidden units): the PyTorch-ROCm restatement of the cell (north_star keeps the encoder in PyTorch)
+            return self.rnn(xin.permute(1, 0, 2).contiguous().to(self.rnn.weights.dtype))
         if not self.TRAIN_KERNELS:
             return self.rnn(xin.permute(1, 0, 2).contiguous())
         r = self.rnn

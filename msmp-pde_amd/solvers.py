@@ -246,6 +246,8 @@ class _SolverBase(nn.Module):
             return self._embed_hip(u, pos_x, variables)
         if isinstance(self.embedding_lem, LEMS):       # stateful encoder: always the state-taking recurrence kernel
             return self.lemoutput_mlp(self.embedding_lem.forward_nodes(self._step_inputs(u, pos_x, pos_t, variables, dt)))
+        if self.hidden_features != 128:     # the GLU classes: LEM cell and lemoutput_mlp as PyTorch-ROCm ops (any width; lem.LEM.forward_nodes)
+            return self.lemoutput_mlp(self.embedding_lem.forward_nodes(self._step_inputs(u, pos_x, pos_t, variables, dt)))
         grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.embedding_lem.parameters())
         if not grad:                    # step inputs assembled inside the kernel (no [N, T, ninp] tensor)
             h = self.embedding_lem.encode_nodes(u, pos_x, pos_t, variables, dt, self.TWO_D, self.lemoutput_mlp)
@@ -381,7 +383,7 @@ class _SolverBase(nn.Module):
         gs = structure_of(data)
         tw = self.time_window
         # the [u | pos | vars] columns of message_net_1's input do not change over the layers: packed once for the tile kernel
-        want_feat = not torch.is_grad_enabled() and gs.tiles() is not None
+        want_feat = not torch.is_grad_enabled() and self.hidden_features == 128 and gs.tiles() is not None
         prep = self._prepare(data, want_feat) if u_in.is_cuda else None
         if prep is not None:            # one HIP launch
             u, pos_x, pos_t, variables, feat = prep
@@ -406,6 +408,9 @@ class _SolverBase(nn.Module):
             gate = self.gnn_layers_gate[i] if self.GATED else None
             h = mp_layer(h, u, pos_x, variables, gs, self.gnn_layers[i], gate, feat=feat)
 
+        return self._decode(h, u, u_in, dt, tw)
+
+    def _decode(self, h, u, u_in, dt, tw):
         grad_path = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.output_mlp.parameters()))
         if self.TWO_D and grad_path:    # models_gnn2D.py:125-141
             diff = _decoder_autograd(self.double_mlp(h), self.output_mlp[0], self.output_mlp[2])
@@ -554,6 +559,48 @@ class MP_PDE_Solver2DLEMLinG2(_SolverBase):
     TWO_D, LEM_ENCODER, G2, LAYER = True, True, True, GNN_LayerLin
 
 
+class _GLUBase(_SolverBase):
+    """The 'GLU' classes (train.py names 'MSGMP-PDE' / 'MSGMP-PDE2D'): the gated LEM model at hidden width 164 whose decoder is a
+    gated pair of CNNs on the two halves of the hidden state,  out = (1 - scale) u_last + cumsum(dt) scale diff  with
+    scale = output_mlp_gate(h[..., :82]), diff = output_mlp_diff(h[..., 82:])  (experiments/models_gnn.py:1379-1523,
+    models_gnn2D.py:1198-1366; no sigmoid on `scale`, as in the reference).  Layers: the width-generic HIP path
+    (layers._mp_layer_wide); LEM cell, lemoutput_mlp, double_mlp and the two small CNNs: PyTorch-ROCm ops."""
+    GATED, LEM_ENCODER, LAYER = True, True, GNN_LayerLin
+
+    def __init__(self, pde, time_window=25, hidden_features=164, hidden_layer=6, eq_variables={}, save_state=None):
+        super().__init__(pde, time_window, hidden_features, hidden_layer, eq_variables, save_state)
+        comps = 2 if self.TWO_D else 1
+        assert time_window == 25, 'the GLU decoder of the reference exists for time_window 25 (Conv1d(.., 8, 6, stride 2) -> Conv1d(8, .., 15) on 82 features)'
+        del self.output_mlp
+        mk = lambda: nn.Sequential(_Conv1dNoMIOpen(comps, 8, 6, stride=2, dtype=torch.float32), Swish(),
+                                   _Conv1dNoMIOpen(8, comps, 15, stride=1, dtype=torch.float32))
+        self.output_mlp_gate = mk()
+        self.output_mlp_diff = mk()
+
+    def _decode(self, h, u, u_in, dt, tw):
+        half = h.shape[1] // 2
+        if self.TWO_D:                  # models_gnn2D.py:1349-1366
+            hd = self.double_mlp(h)                                             # [N, 2, W]
+            half = hd.shape[2] // 2
+            diff = self.output_mlp_diff(hd[:, :, half:])
+            scale = self.output_mlp_gate(hd[:, :, :half])
+            out = ((1.0 - scale) * u.view(-1, 2, tw) + dt.view(1, 1, tw) * scale * diff).flatten(1, 2)
+        else:                           # models_gnn.py:1511-1521
+            scale = self.output_mlp_gate(h[:, :half][:, None]).squeeze(1)
+            diff = self.output_mlp_diff(h[:, half:][:, None]).squeeze(1)
+            out = (1.0 - scale) * u[:, -1:] + dt.view(1, tw) * (scale * diff)
+        return out.to(u_in.dtype)
+
+
+class MP_PDE_SolverLEMLinGatedGLU(_GLUBase):
+    """experiments/models_gnn.py:1379-1523 (train.py name 'MSGMP-PDE')."""
+
+
+class MP_PDE_Solver2DLEMLinGatedGLU(_GLUBase):
+    """experiments/models_gnn2D.py:1198-1366 (train.py name 'MSGMP-PDE2D')."""
+    TWO_D = True
+
+
 class MP_PDE_SolverLEMLinGatedSave(_SolverBase):
     """experiments/models_gnn.py:1747-1905 (train.py name 'SaveMSMP-PDE'): MSMP-PDE whose LEM keeps its hidden states from one
     call of a rollout to the next (`model.embedding_lem.reset_states()` between sequences)."""
@@ -614,4 +661,5 @@ MODEL_NAMES = {   # experiments/train.py:34-183 getModel names -> class
     'MSSMP-PDE': MSSMP_PDE_Solver, 'SaveMSMP-PDE': MP_PDE_SolverLEMLinGatedSave,
     'LSTM': MP_PDE_SolverLSTMLin, 'LSTMGated': MP_PDE_SolverLSTMLinGated, 'LSTM2D': MP_PDE_Solver2DLSTMLin,
     'LSTMGated2D': MP_PDE_Solver2DLSTMLinGated,
+    'MSGMP-PDE': MP_PDE_SolverLEMLinGatedGLU, 'MSGMP-PDE2D': MP_PDE_Solver2DLEMLinGatedGLU,
 }

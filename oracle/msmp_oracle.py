@@ -165,10 +165,10 @@ def lstm_forward(inputs, w_ih, w_hh, b_ih, b_hh):
 # solver forward passes
 # --------------------------------------------------------------------------------------------
 KINDS_1D = ('MP_PDE_Solver', 'MP_PDE_SolverGated', 'MP_PDE_SolverLEMLinGated', 'MP_PDE_SolverLEMLin', 'MSSMP_PDE_Solver',
-            'MP_PDE_SolverLEMLinGatedSave',
+            'MP_PDE_SolverLEMLinGatedSave', 'MP_PDE_SolverLEMLinGatedGLU',
             'MP_PDE_SolverLSTMLin', 'MP_PDE_SolverLSTMLinGated')
 KINDS_2D = ('MP_PDE_Solver2D', 'MP_PDE_Solver2DGated', 'MP_PDE_Solver2DLEMLinGated', 'MP_PDE_Solver2DLEMLin',
-            'MP_PDE_Solver2DLEMLinG2', 'MP_PDE_Solver2DLSTMLin', 'MP_PDE_Solver2DLSTMLinGated')
+            'MP_PDE_Solver2DLEMLinG2', 'MP_PDE_Solver2DLSTMLin', 'MP_PDE_Solver2DLSTMLinGated', 'MP_PDE_Solver2DLEMLinGatedGLU')
 
 _DECODER = {  # time_window -> (k1, stride1, k2); experiments/models_gnn.py:210-224, models_gnn2D.py:79-88
     20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}
@@ -213,6 +213,8 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
     MP_PDE_Solver2DLEMLinG2     experiments/models_gnn2D.py:565-620   (gradient-gated blend; train.py 'MSG2-PDE2D')
     MP_PDE_SolverLEMLinGatedSave  experiments/models_gnn.py:1747-1905 (and save_state=True of the 2-D class): pass a dict as
                                 `lem_states`; it carries the LEM states from call to call ({} or reset = a new sequence)
+    MP_PDE_SolverLEMLinGatedGLU   experiments/models_gnn.py:1379-1523   (hidden width 164, gated CNN decoder; train.py 'MSGMP-PDE')
+    MP_PDE_Solver2DLEMLinGatedGLU experiments/models_gnn2D.py:1198-1366 (same, 2-D; train.py 'MSGMP-PDE2D')
     MSSMP_PDE_Solver            experiments/models_gnn.py:1721-1745   (two MSMP-PDE networks `diff.*`, `scale.*`, each returning
                                 its decoder output (:1679-1682, decoder_diff=True); train.py 'MSSMP-PDE')
     `sd` maps the reference's state_dict key names to arrays.  Row S1."""
@@ -285,6 +287,23 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
             h = mp_layer(pm, h, u, pos_x, variables, ei, batch, lin=False)
         hs.append(h)
 
+    if kind.endswith('GLU'):
+        # the GLU classes (hidden width 164): a gated pair of CNNs on the two halves of the hidden state; `scale` enters WITHOUT a
+        # sigmoid.  1-D: experiments/models_gnn.py:1511-1521; 2-D: models_gnn2D.py:1349-1366 (double_mlp first, halves of each component)
+        dec = lambda x, pre: conv1d(swish(conv1d(x, sd[pre + '.0.weight'], sd[pre + '.0.bias'], 2)), sd[pre + '.2.weight'], sd[pre + '.2.bias'], 1)
+        if two_d:
+            hd = swish(linear(h, sd['double_mlp.0.weight'], sd['double_mlp.0.bias'])).reshape(-1, 2, h.shape[1])
+            half = hd.shape[2] // 2
+            diff, scale = dec(hd[:, :, half:], 'output_mlp_diff'), dec(hd[:, :, :half], 'output_mlp_gate')
+            out = ((1.0 - scale) * u.reshape(-1, 2, tw) + dt[None, None, :] * scale * diff).reshape(-1, 2 * tw)
+        else:
+            half = h.shape[1] // 2
+            scale = dec(h[:, None, :half], 'output_mlp_gate')[:, 0, :]
+            diff = dec(h[:, None, half:], 'output_mlp_diff')[:, 0, :]
+            out = (1.0 - scale) * u[:, -1:] + dt[None, :] * (scale * diff)
+        if parts:
+            return SimpleNamespace(out=out, h_enc=h_enc, hs=hs)
+        return out
     k1, s1, k2 = _DECODER[tw]
     if two_d:       # models_gnn2D.py:125-141
         hd = swish(linear(h, sd['double_mlp.0.weight'], sd['double_mlp.0.bias'])).reshape(-1, 2, h.shape[1])

@@ -119,6 +119,19 @@ def solver_forward(kind, sd, data, pde, time_window, eq_variables, hidden_layer=
             h = (1.0 - tau) * h + tau * swish(mp_layer(sd, f'gnn_layers.{i}.', h, u, pos_x, variables, ei, batch, b, True))
         else:
             h = mp_layer(sd, f'gnn_layers.{i}.', h, u, pos_x, variables, ei, batch, b, False)
+    if kind.endswith('GLU'):        # msmp_oracle.solver_forward, GLU branch
+        dec = lambda x, pre: F.conv1d(swish(F.conv1d(x, sd[pre + '.0.weight'], sd[pre + '.0.bias'], stride=2)), sd[pre + '.2.weight'], sd[pre + '.2.bias'])
+        if two_d:
+            hd = swish(F.linear(h, sd['double_mlp.0.weight'], sd['double_mlp.0.bias'])).reshape(-1, 2, h.shape[1])
+            half = hd.shape[2] // 2
+            diff, scale = dec(hd[:, :, half:], 'output_mlp_diff'), dec(hd[:, :, :half], 'output_mlp_gate')
+            out = ((1.0 - scale) * u.reshape(-1, 2, tw) + dt[None, None, :] * scale * diff).reshape(-1, 2 * tw)
+        else:
+            half = h.shape[1] // 2
+            scale = dec(h[:, None, :half], 'output_mlp_gate')[:, 0, :]
+            diff = dec(h[:, None, half:], 'output_mlp_diff')[:, 0, :]
+            out = (1.0 - scale) * u[:, -1:] + dt[None, :] * (scale * diff)
+        return out.detach().cpu().numpy() if as_numpy else out
     k1, s1, k2 = O._DECODER[tw]
     if two_d:
         hd = swish(F.linear(h, sd['double_mlp.0.weight'], sd['double_mlp.0.bias'])).reshape(-1, 2, h.shape[1])

@@ -551,6 +551,74 @@ def test_lem_encoder_in_kernel_input_assembly(mp, two_d, nv, tw, n):
             mp.lib().msmp_tune(b'lem', 4)
 
 
+@pytest.mark.parametrize('rows,k,n_out,mode', [(300, 192, 164, 0), (1000, 164, 164, 1), (129, 331, 164, 1), (77, 28, 5, 0), (640, 356, 300, 2), (1, 4, 128, 1)])
+def test_general_linear_kernel(mp, rows, k, n_out, mode):
+    """msmp_linear_f32 (the GLU classes' GEMMs: any K, any number of output channels, padded columns written as f(0)): against
+    float64, incl. ragged row tiles, K that is no multiple of 4 / 32, a partial last 128-column group and the accumulate mode."""
+    from msmp_pde_amd._lib import check, ptr, current_stream
+    L = mp.lib()
+    rng = np.random.default_rng(rows + k)
+    ldx = (k + 3) // 4 * 4 + 4
+    ld_out = 128 * ((n_out + 127) // 128) + 8
+    x = torch.tensor(rng.standard_normal((rows, ldx)), dtype=torch.float32).cuda()
+    w = torch.tensor(rng.standard_normal((n_out, k)) / np.sqrt(k), dtype=torch.float32).cuda()
+    b = torch.tensor(rng.standard_normal(n_out), dtype=torch.float32).cuda()
+    out = torch.full((rows, ld_out), 0.25, dtype=torch.float32, device='cuda')
+    ws = torch.empty(L.msmp_linear_workspace_bytes(k, n_out), dtype=torch.uint8, device='cuda')
+    check(L.msmp_linear_f32(ptr(x), ldx, rows, k, ptr(w), k, ptr(b), n_out, mode, ptr(out), ld_out, ptr(ws), ws.numel(), current_stream()), 'linear')
+    acc = x[:, :k].double().cpu().numpy() @ w.double().cpu().numpy().T
+    ref = {0: acc + b.double().cpu().numpy(), 1: O.swish(acc + b.double().cpu().numpy()), 2: acc + 0.25}[mode]
+    got = out.double().cpu().numpy()
+    assert np.abs(got[:, :n_out] - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+    groups = 128 * ((n_out + 127) // 128)
+    assert np.all(got[:, n_out:groups] == (0.25 if mode == 2 else 0.0))        # padded columns: f(0 + 0) (accumulate: untouched values + 0)
+    assert np.all(got[:, groups:] == 0.25)                                      # beyond the groups: untouched
+
+
+def test_wide_layer_pieces_vs_oracle(mp):
+    """The width-generic layer (hidden width 164; layers._mp_layer_wide = msmp_linear_f32 + wide_kernels.hip) against the float64
+    oracle layer and against its PyTorch-ROCm autograd twin, gated and plain, on a ragged batch with zero in-degree nodes."""
+    from msmp_pde_amd.layers import _mp_layer_wide, _mp_layer_wide_autograd
+    from msmp_pde_amd.graph import GraphStructure
+    rng = np.random.default_rng(3)
+    W, tw, nv = 164, 25, 2
+    sizes = [1, 37, 100, 130, 5]
+    n = sum(sizes)
+    batch = np.repeat(np.arange(len(sizes)), sizes)
+    starts = np.concatenate(([0], np.cumsum(sizes)))
+    src, dst = [], []
+    for g, sz in enumerate(sizes):
+        for t in range(sz):
+            if t % 7 == 3:
+                continue                                            # zero in-degree
+            for s_ in rng.choice(sz, size=min(sz, int(rng.integers(1, 6))), replace=False):
+                src.append(starts[g] + s_); dst.append(starts[g] + t)
+    order = np.argsort(np.array(dst), kind='stable')
+    ei = np.stack([np.array(src)[order], np.array(dst)[order]])
+    gs = GraphStructure(torch.tensor(ei).cuda(), torch.tensor(batch).cuda(), n)
+    torch.manual_seed(5)
+    main = mp.GNN_LayerLin(W, W, W, tw, nv).cuda()
+    gate = mp.GNN_LayerLin(W, W, W, tw, nv).cuda()
+    h = torch.tensor(rng.standard_normal((n, W)), dtype=torch.float32).cuda()
+    u = torch.tensor(rng.standard_normal((n, tw)), dtype=torch.float32).cuda()
+    pos = torch.tensor(rng.uniform(0, 1, (n, 1)), dtype=torch.float32).cuda()
+    var = torch.tensor(rng.uniform(0, 1, (n, nv)), dtype=torch.float32).cuda()
+    sdm = {k: v.detach().double().cpu().numpy() for k, v in main.state_dict().items()}
+    sdg = {k: v.detach().double().cpu().numpy() for k, v in gate.state_dict().items()}
+    args64 = [t.double().cpu().numpy() for t in (h, u, pos, var)]
+    pm, pg = O.layer_params(sdm, ''), O.layer_params(sdg, '')
+    ref_plain = O.mp_layer(pm, *args64, ei, batch, lin=True)
+    tau = O.sigmoid(O.mp_layer(pg, *args64, ei, batch, lin=True))
+    ref_gated = (1.0 - tau) * args64[0] + tau * O.swish(ref_plain)
+    with torch.no_grad():
+        for g_, ref in ((None, ref_plain), (gate, ref_gated)):
+            out = _mp_layer_wide(h, u, pos.reshape(-1), var, gs, main, g_, 1e-5)
+            twin = _mp_layer_wide_autograd(h, u, pos, var, gs, main, g_, 1e-5)
+            e1, e2 = np.abs(out.double().cpu().numpy() - ref).max(), np.abs(twin.double().cpu().numpy() - ref).max()
+            print(f'wide layer ({"gated" if g_ is not None else "plain"}): hip {e1:.2e}, torch twin {e2:.2e}')
+            assert e1 < 2e-5 and e2 < 2e-5
+
+
 def test_guard_bands_are_active(mp):
     """The conftest fixture really wraps the allocations the host layer makes (torch.empty / empty_like on the GPU) in
     sentinel bands: a kernel output sits 256 elements into a larger buffer whose margins are checked after each test."""

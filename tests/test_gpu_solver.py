@@ -135,7 +135,9 @@ def test_full_depth_vs_reference_golden(mp, kind, exp):
                                       ('MP_PDE_SolverLEMLin', 'E2'), ('MP_PDE_Solver2DLEMLin', 'MSWG3'),
                                       ('MP_PDE_Solver2DLEMLinG2', 'RPU'), ('MSSMP_PDE_Solver', 'E2'),
                                       ('MP_PDE_SolverLSTMLinGated', 'E2'), ('MP_PDE_SolverLSTMLin', 'WE3'),
-                                      ('MP_PDE_Solver2DLSTMLinGated', 'RPU'), ('MP_PDE_Solver2DLSTMLin', 'MSWG3')])
+                                      ('MP_PDE_Solver2DLSTMLinGated', 'RPU'), ('MP_PDE_Solver2DLSTMLin', 'MSWG3'),
+                                      ('MP_PDE_SolverLEMLinGatedGLU', 'E2'), ('MP_PDE_SolverLEMLinGatedGLU', 'WE3'),      # hidden width 164: the width-generic layer path
+                                      ('MP_PDE_Solver2DLEMLinGatedGLU', 'MSWG3'), ('MP_PDE_Solver2DLEMLinGatedGLU', 'RPU')])
 def test_full_depth_vs_oracle(mp, kind, exp):
     """The solver classes at the default depth (6 layers / 6 gated pairs) on 8 graphs, default init,
     against the float64 oracle: the accumulated fp32 error must stay inside the 1e-5 output bar."""

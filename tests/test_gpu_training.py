@@ -28,7 +28,8 @@ def mp():
                                       ('MP_PDE_SolverLEMLin', 'E2'), ('MP_PDE_Solver2DLEMLinG2', 'RPU'),
                                       ('MSSMP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'WE3'), ('MP_PDE_SolverLEMLinGated', 'WE3'),
                                       ('MP_PDE_Solver2DLEMLinGated', 'MSWG3'), ('MP_PDE_Solver2D', 'RPU'),
-                                      ('MP_PDE_SolverLSTMLinGated', 'E2'), ('MP_PDE_Solver2DLSTMLin', 'RPU')])
+                                      ('MP_PDE_SolverLSTMLinGated', 'E2'), ('MP_PDE_Solver2DLSTMLin', 'RPU'),
+                                      ('MP_PDE_SolverLEMLinGatedGLU', 'E2'), ('MP_PDE_Solver2DLEMLinGatedGLU', 'MSWG3')])
 def test_gradients_match_float64_oracle(mp, kind, exp):
     """d loss / d parameters of the product (HIP forward, recompute backward, fp32) against torch autograd through
     the float64 oracle, for the reference's training loss sqrt(sum (pred - y)^2) (train_helper.py:126,138)."""

@@ -113,6 +113,36 @@ def test_state_dict_is_reference_compatible(mp, kind):
     assert repr(model) == 'GNN' and model.eq_variables == eqv
 
 
+@pytest.mark.parametrize('kind,comps', [('MP_PDE_SolverLEMLinGatedGLU', 1), ('MP_PDE_Solver2DLEMLinGatedGLU', 2)])
+def test_glu_classes_have_the_reference_layout(mp, kind, comps):
+    """The GLU classes cannot be instantiated from the reference here (their LEM needs the absent lem_cuda), so the
+    state_dict layout is checked against the constructor arithmetic of experiments/models_gnn.py:1379-1462 /
+    models_gnn2D.py:1198-1296: hidden width 164, GNN_LayerLin with time_window = comps * 25, LEM(2 + len(eq_variables) + comps, 164),
+    two decoders Conv1d(comps, 8, 6, stride 2) -> Conv1d(8, comps, 15)."""
+    eqv = {'beta': 0.2} if comps == 1 else {'a': 1.0, 'b': 1.0}
+    nv, W, tw = len(eqv) + 1, 164, 25 * comps
+    model = getattr(mp, kind)(mp.CE() if comps == 1 else mp.AD(), time_window=25, eq_variables=eqv, hidden_layer=2)
+    sd = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    want = {}
+    for stack in ('gnn_layers', 'gnn_layers_gate'):
+        for i in range(2):
+            pre = f'{stack}.{i}.'
+            want.update({pre + 'message_net_1.0.weight': (W, 2 * W + tw + 1 + nv), pre + 'message_net_1.0.bias': (W,),
+                         pre + 'message_net_2.0.weight': (W, W), pre + 'message_net_2.0.bias': (W,),
+                         pre + 'update_net_1.0.weight': (W, 2 * W + nv), pre + 'update_net_1.0.bias': (W,),
+                         pre + 'update_net_2.0.weight': (W, W), pre + 'update_net_2.0.bias': (W,)})
+    ninp = 2 + len(eqv) + comps
+    want.update({'embedding_lem.rnn.weights': (3 * W, ninp + W), 'embedding_lem.rnn.weights_lin_z': (W, ninp + W),
+                 'embedding_lem.rnn.bias': (3 * W,), 'embedding_lem.rnn.bias_lin_z': (W,),
+                 'lemoutput_mlp.0.weight': (W, W), 'lemoutput_mlp.0.bias': (W,), 'lemoutput_mlp.2.weight': (W, W), 'lemoutput_mlp.2.bias': (W,)})
+    if comps == 2:
+        want.update({'double_mlp.0.weight': (2 * W, W), 'double_mlp.0.bias': (2 * W,)})
+    for dec in ('output_mlp_gate', 'output_mlp_diff'):
+        want.update({dec + '.0.weight': (8, comps, 6), dec + '.0.bias': (8,), dec + '.2.weight': (comps, 8, 15), dec + '.2.bias': (comps,)})
+    assert sd == want
+    assert repr(model) == 'GNN' and mp.MODEL_NAMES['MSGMP-PDE' if comps == 1 else 'MSGMP-PDE2D'] is type(model)
+
+
 def test_parameter_counts_match_survey(mp):
     """SURVEY.md section 8 config table (measured on the reference)."""
     n = lambda m: sum(p.numel() for p in m.parameters())
