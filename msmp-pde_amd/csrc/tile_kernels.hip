@@ -62,6 +62,7 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
     __shared__ int s_first[TILE_EDGES];     // 1: first occurrence of an out-of-range source
     __shared__ int s_slot[TILE_EDGES];
     __shared__ int s_halo[5];               // lo start, lo count, hi start, hi count, ranged
+    __shared__ int s_stat[6];
     const int t = blockIdx.x, k = threadIdx.x;
     const int n0 = t * tile_nodes, n1 = min(n0 + tile_nodes, n_nodes);
     const int nt = n1 - n0;
@@ -83,19 +84,21 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
             if (s_col[i] == j) { first = 0; owner = i; break; }
     }
     s_first[k] = first;
+    if (k < 6) s_stat[k] = (k == 0 || k == 3) ? 0x7fffffff : (k == 1 || k == 4) ? -1 : 0;     // lo min, lo max, lo count, hi min, hi max, hi count
     __syncthreads();
     // "Ranged" tile: the sources outside the tile form at most one run of consecutive nodes below it and one above it (every
     // interior tile of a banded 1-D graph).  Their slots are then numbered in ascending node order and the message kernel
     // computes the node of a slot ARITHMETICALLY from four integers it reads with one scalar load (tile_halo), instead of reading
     // the node list first and the rows second (two dependent global reads at the head of every tile).
+    if (first) {
+        int* st3 = s_stat + (j < n0 ? 0 : 3);
+        atomicMin(st3, j);
+        atomicMax(st3 + 1, j);
+        atomicAdd(st3 + 2, 1);
+    }
+    __syncthreads();
     if (k == 0) {
-        int lo_min = 0x7fffffff, lo_max = -1, lo_cnt = 0, hi_min = 0x7fffffff, hi_max = -1, hi_cnt = 0;
-        for (int i = 0; i < TILE_EDGES; ++i)
-            if (s_first[i]) {
-                const int v = s_col[i];
-                if (v < n0) { lo_min = min(lo_min, v); lo_max = max(lo_max, v); ++lo_cnt; }
-                else { hi_min = min(hi_min, v); hi_max = max(hi_max, v); ++hi_cnt; }
-            }
+        const int lo_min = s_stat[0], lo_max = s_stat[1], lo_cnt = s_stat[2], hi_min = s_stat[3], hi_max = s_stat[4], hi_cnt = s_stat[5];
         const bool ranged = (lo_cnt == 0 || lo_max - lo_min + 1 == lo_cnt) && (hi_cnt == 0 || hi_max - hi_min + 1 == hi_cnt);
         s_halo[0] = lo_cnt ? lo_min : 0; s_halo[1] = lo_cnt; s_halo[2] = hi_cnt ? hi_min : 0; s_halo[3] = hi_cnt; s_halo[4] = ranged;
     }
@@ -125,9 +128,7 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
         edge_slot[(size_t)t * TILE_EDGES + k] = 0;           // lanes without an edge read a valid slot pair; their messages are never summed
     if (k < TILE_NCAP && k < nt) tile_node[(size_t)t * TILE_NCAP + k] = n0 + k;
     __syncthreads();
-    int total = nt;
-    if (k == 0 || k < TILE_NCAP)
-        for (int i = 0; i < TILE_EDGES; ++i) total += s_first[i];
+    const int total = nt + s_stat[2] + s_stat[5];           // targets + distinct outside sources
     if (k == 0) {
         tile_count[t] = min(total, TILE_NCAP);
         const bool use = ranged && total <= TILE_NCAP;
