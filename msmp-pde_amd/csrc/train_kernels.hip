@@ -864,9 +864,101 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RgArgs a) {
     }
 }
 
+// Small-batch edition (round 3; VERDICT r02 item 6a: below 32 768 rows the 128-row workgroups above fill a fraction of the chip
+// and the layer backward went to rocblas_sgemm): a workgroup owns 32 rows and its four waves split the OUTPUT: wave w computes
+// channel tile T = w (the channels 4 c + w of the dealt fragment layout) of the same 32 rows -- a quarter of the MFMAs per wave,
+// four times the workgroups, the wave's weight fragments straight from the L2-resident pack (6 x 16 bytes per lane and chunk),
+// no LDS, no barrier.  Same fragments, same arithmetic order per output element as rows_gemm_kernel: bit-identical results.
+template <int EPI>
+__global__ __launch_bounds__(256) void rows_gemm_small_kernel(RgArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int T = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const long row0 = (long)blockIdx.x * 32;
+    const long xr = min(row0 + c, a.rows - 1);
+    const float* xrow = a.x + (size_t)xr * a.ldx + 8 * hh;
+    auto load_x = [&](int ch, f32x4 (&dst)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 32 * ch + 16 * (i >> 1) + 8 * hh + 4 * (i & 1);
+            if (k + 4 <= a.K) dst[i] = *reinterpret_cast<const f32x4*>(xrow + 32 * ch + 16 * (i >> 1) + 4 * (i & 1));
+            else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) dst[i][m] = k + m < a.K ? xrow[32 * ch + 16 * (i >> 1) + 4 * (i & 1) + m] : 0.f;
+            }
+        }
+    };
+    auto load_w = [&](int ch, u32x4 (&dst)[6]) {
+        const u32x4* src = a.wfrag + (size_t)ch * RG_CHUNK_U4 + lane;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) dst[3 * s + pl] = src[(size_t)((s * 4 + T) * 3 + pl) * 64];
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4 xa[4], xb[4];
+    u32x4 wa[6], wb[6];
+    auto chunk_mma = [&](const f32x4 (&xv)[4], const u32x4 (&w)[6]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float v[8] = {xv[2 * s][0], xv[2 * s][1], xv[2 * s][2], xv[2 * s][3], xv[2 * s + 1][0], xv[2 * s + 1][1], xv[2 * s + 1][2], xv[2 * s + 1][3]};
+            const Bf3 x3 = split_bf16x3(v);
+            const bf16x8 whi = __builtin_bit_cast(bf16x8, w[3 * s]), wmid = __builtin_bit_cast(bf16x8, w[3 * s + 1]), wlo = __builtin_bit_cast(bf16x8, w[3 * s + 2]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3.lo, whi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3.hi, wlo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3.mid, wmid, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3.mid, whi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3.hi, wmid, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3.hi, whi, acc, 0, 0, 0);
+        }
+    };
+    load_w(0, wa);
+    load_x(0, xa);
+    for (int ch = 0; ch < a.n_chunks; ch += 2) {
+        if (ch + 1 < a.n_chunks) { load_w(ch + 1, wb); load_x(ch + 1, xb); }
+        chunk_mma(xa, wa);
+        if (ch + 1 < a.n_chunks) {
+            if (ch + 2 < a.n_chunks) { load_w(ch + 2, wa); load_x(ch + 2, xa); }
+            chunk_mma(xb, wb);
+        }
+    }
+    // epilogue: lane c holds channel 4 c + T of rows row0 + acc_row(r, hh)
+    const int chn = 4 * c + T;
+    float bias1 = 0.f;
+    if (EPI <= 1 || EPI == 4) bias1 = a.bias[chn];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long row = row0 + acc_row(r, hh);
+        if (row >= a.rows) continue;
+        float v = acc[r];
+        if (EPI <= 1 || EPI == 4) v += bias1;
+        if (EPI == 4) v = swishf(v);
+        if (EPI == 2) v *= dswish(a.aux[(size_t)row * H + chn]);
+        if (EPI == 5) v += a.out0[(size_t)row * a.ld0 + chn];
+        a.out0[(size_t)row * a.ld0 + chn] = v;
+        if (EPI == 0) a.out1[(size_t)row * H + chn] = swishf(v);
+    }
+}
+
+constexpr long RG_SMALL_ROWS = 32768;      // below this many rows the 32-row workgroups fill the chip better (294 x 4 waves at E = 9 408)
+
 static int rows_gemm(int epi, const float* x, int ldx, long rows, int K, const u32x4* wfrag, const float* bias, const float* aux, float* out0,
                      int ld0, float* out1, hipStream_t st) {
     RgArgs a{x, wfrag, bias, aux, out0, out1, rows, ldx, K, (K + 31) / 32, ld0};
+    if (rows < RG_SMALL_ROWS) {
+        const dim3 gs((unsigned)((rows + 31) / 32));
+        switch (epi) {
+            case 0: hipLaunchKernelGGL(rows_gemm_small_kernel<0>, gs, dim3(256), 0, st, a); break;
+            case 1: hipLaunchKernelGGL(rows_gemm_small_kernel<1>, gs, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL(rows_gemm_small_kernel<2>, gs, dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL(rows_gemm_small_kernel<4>, gs, dim3(256), 0, st, a); break;
+            case 5: hipLaunchKernelGGL(rows_gemm_small_kernel<5>, gs, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL(rows_gemm_small_kernel<3>, gs, dim3(256), 0, st, a); break;
+        }
+        return check_launch("rows_gemm_small_kernel");
+    }
     const dim3 grid((unsigned)((rows + 127) / 128));
     switch (epi) {
         case 0: hipLaunchKernelGGL(rows_gemm_kernel<0>, grid, dim3(256), 0, st, a); break;
@@ -1158,7 +1250,7 @@ extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, cons
     // rows_gemm_kernel from 32 768 edges on (measured E2 MSMP-PDE, ms per training iteration, library / own: batch 16 5.6 / 6.5,
     // batch 128 12.8 / 12.1, batch 512 39.0 / 34.0: below that the 128-row workgroups do not fill the chip); tune "bwd_gemm": 0 never, 2 always
     const int bg_mode = msmp_tune_get("bwd_gemm");
-    const bool own_gemm = bg_mode == 2 || (bg_mode == 1 && n_edges >= 32768);
+    const bool own_gemm = bg_mode != 0;        // 0: rocblas_sgemm (kept for A/B runs); the library is never loaded otherwise
     static Blas none;
     Blas& bl = own_gemm ? none : blas();
     hipStream_t st = (hipStream_t)stream;
