@@ -81,13 +81,15 @@ int msmp_last_status(int* flags_out, int reset);
  *   "tile"    2 (default): with node tiles that are at least 60 % full (>= 76 edges per tile on average), project P / Q inside the message
  *             kernel, else the gather kernels; 3: the same regardless of the fill; 1: msmp_node_project_f32 + tile kernel on the
  *             staged P / Q rows; 0: ignore the tiles (gather kernels).
- *   "bwd_gemm" 1 (default): msmp_mp_layer_bwd_f32 runs its row GEMMs on its own bf16x3 MFMA kernel (fused bias / Swish / dSwish epilogues) from
- *             32 768 edges on and on rocblas_sgemm below; 0: always the library; 2: always its own kernel.
+ *   "bwd_gemm" 1 (default) / 2: msmp_mp_layer_bwd_f32 runs its row GEMMs on its own bf16x3 MFMA kernels (fused bias / Swish / dSwish epilogues;
+ *             128-row workgroups from 32 768 rows on, 32-row workgroups whose waves split the output channels below);
+ *             0: rocblas_sgemm + separate epilogue passes (A/B runs only: librocblas is loaded on first use).
  *   "tile_arith" 1 (default): ranged tiles take their node rows by arithmetic on tile_halo; 0: always through the node list.
  *   "tail"    1 (default): msmp_mp_layer_f32 uses msmp_node_tail_f32 for graphs of up to 128 nodes; 0: the piecewise kernels.
  *   "pair"    gated pair: both heads' projection / message kernels in one launch each (bit-identical results): 0 never,
  *             1 (default) for batches of up to 65 536 nodes, where a step is bound by the latency of its ~60 dependent launches, 2 always.
- *   "lem"     LEM encoder edition (3 weight-stationary, default; 1 / 2 streamed-weight split kernels; 0 fp32 MFMA). */
+ *   "lem"     LEM encoder edition: 4 (default) weight-stationary, three node tiles, matrix / vector halves of a SIMD's two waves in
+ *             anti-phase; 3 the two-tile weight-stationary kernel of round 2; 0 fp32 MFMA ("split" 1 / 0 selects 4 / 0). */
 int msmp_tune(const char* key, int value);
 int msmp_tune_query(const char* key);      /* current value of "split", "tail", "pair", "bwd_gemm", "tile", "tile_arith" (0 for other keys) */
 

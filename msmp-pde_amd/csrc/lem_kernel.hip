@@ -278,368 +278,6 @@ __global__ __launch_bounds__(256) void lem_encoder_kernel(LemArgs a) {
 
 
 // ----------------------------------------------------------------------------------------------
-// fp16-split edition (mfma_tiles.h): same recurrence, the four K = 128 GEMMs per step on the fp16 matrix pipe.
-// The states stay fp32 in accumulator layout; y is split into hi/lo fragments once per step (shared by the three
-// gate GEMMs), z once (for the lin GEMM, in the same registers).  Input columns remain NS fp32 MFMA k-steps, with
-// bias and fragments pre-multiplied by the matrix's 2^s so that they accumulate into the same scaled accumulator.
-// ----------------------------------------------------------------------------------------------
-struct LemSplitArgs {
-    LemArgs b;            // rec / mlp point at the SPLIT chunks, bias / wx / mlpb at the pre-scaled copies
-    const float* scales;  // [8]
-};
-
-template <int NS>
-__device__ __forceinline__ void lem_acc_init_s(const LemArgs& a, int grp, int lane, int hh, const float (&x)[2 * NS],
-                                               f32x16 (&acc)[4][1]) {
-    acc_init_bias<1>(a.bias + H * grp, hh, acc);
-    const float* wf = a.wx + (size_t)grp * 1024 + lane;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const float b = hh ? x[2 * s + 1] : x[2 * s];
-#pragma unroll
-        for (int T = 0; T < 4; ++T)
-            acc[T][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[(T * 4 + s) * 64], b, acc[T][0], 0, 0, 0);
-    }
-}
-
-template <int NS>
-__global__ __launch_bounds__(256) void lem_encoder_split_kernel(LemSplitArgs sa) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS];
-    const LemArgs& a = sa.b;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 31, hh = lane >> 5;
-    const long n = (long)blockIdx.x * 128 + wave * 32 + c;
-    const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
-    const float* xrow = a.xin + (size_t)nc * a.t_len * (2 * NS);
-    const float invW = sa.scales[4], invZ = sa.scales[5];
-
-    f32x16 y[4][1], z[4][1], g[4][1], acc[4][1];
-    half8 sh[4][1][2], sl[4][1][2];            // hi / lo fragments of the state currently used as B operand
-    acc_zero<1>(y);
-    acc_zero<1>(z);
-#pragma unroll
-    for (int T = 0; T < 4; ++T) split_acc_tile<1>(y[T], sh[T], sl[T]);
-
-    WStage ws;
-    wstage_load(ws, a.rec, tid);
-    wstage_store_linear(ws, lds, tid);
-    __syncthreads();
-
-#define LEM_GROUP_S(ACC, BASE, NEXT_AFTER_LAST)                                                        \
-    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                 \
-        const float* nxt = kc < 3 ? a.rec + (size_t)((BASE) + kc + 1) * SPLIT_CHUNK_FLOATS : (NEXT_AFTER_LAST); \
-        wstage_load(ws, nxt, tid);                                                                     \
-        mma_chunk_split<1>(lds + (((BASE) + kc) & 1) * SPLIT_CHUNK_FLOATS, lane, sh[kc], sl[kc], ACC);  \
-        wstage_store_linear(ws, lds + (((BASE) + kc + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);              \
-        __syncthreads();                                                                               \
-    }
-
-    for (int t = 0; t < a.t_len; ++t) {
-        float x[2 * NS];
-#pragma unroll
-        for (int f = 0; f < 2 * NS; ++f) x[f] = xrow[t * (2 * NS) + f];
-        const float* after = t + 1 == a.t_len ? a.mlp : a.rec;
-
-        lem_acc_init_s<NS>(a, 1, lane, hh, x, g);                    // g2 -> dt_
-        LEM_GROUP_S(g, 0, a.rec + 4 * SPLIT_CHUNK_FLOATS)
-#pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[T][0][r] = a.dt * sigmoidf_(g[T][0][r] * invW);
-        lem_acc_init_s<NS>(a, 2, lane, hh, x, acc);                  // g3 -> z update
-        LEM_GROUP_S(acc, 4, a.rec + 8 * SPLIT_CHUNK_FLOATS)
-#pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                z[T][0][r] = (1.0f - g[T][0][r]) * z[T][0][r] + g[T][0][r] * tanhf_(acc[T][0][r] * invW);
-        lem_acc_init_s<NS>(a, 0, lane, hh, x, g);                    // g1 -> dt_bar (still from the y fragments)
-        LEM_GROUP_S(g, 8, a.rec + 12 * SPLIT_CHUNK_FLOATS)
-#pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[T][0][r] = a.dt * sigmoidf_(g[T][0][r] * invW);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) split_acc_tile<1>(z[T], sh[T], sl[T]);      // fragments now hold the new z
-        lem_acc_init_s<NS>(a, 3, lane, hh, x, acc);                  // lin -> y update
-        LEM_GROUP_S(acc, 12, after)
-#pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                y[T][0][r] = (1.0f - g[T][0][r]) * y[T][0][r] + g[T][0][r] * tanhf_(acc[T][0][r] * invZ);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) split_acc_tile<1>(y[T], sh[T], sl[T]);      // fragments of the new y
-    }
-#undef LEM_GROUP_S
-
-    if (a.with_mlp) {
-        const float invA = sa.scales[6], invB = sa.scales[7];
-        acc_init_bias<1>(a.mlpb, hh, acc);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            wstage_load(ws, a.mlp + (size_t)(j + 1) * SPLIT_CHUNK_FLOATS, tid);
-            mma_chunk_split<1>(lds + (j & 1) * SPLIT_CHUNK_FLOATS, lane, sh[j], sl[j], acc);
-            wstage_store_linear(ws, lds + ((j + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
-            __syncthreads();
-        }
-#pragma unroll
-        for (int T = 0; T < 4; ++T) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[T][0][r] = swishf(acc[T][0][r] * invA);
-            split_acc_tile<1>(acc[T], sh[T], sl[T]);
-        }
-        acc_init_bias<1>(a.mlpb + H, hh, y);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j < 3) wstage_load(ws, a.mlp + (size_t)(4 + j + 1) * SPLIT_CHUNK_FLOATS, tid);
-            mma_chunk_split<1>(lds + (j & 1) * SPLIT_CHUNK_FLOATS, lane, sh[j], sl[j], y);
-            if (j < 3) {
-                wstage_store_linear(ws, lds + ((j + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
-                __syncthreads();
-            }
-        }
-#pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) y[T][0][r] = swishf(y[T][0][r] * invB);
-    }
-
-    if (n < a.n_nodes) {
-        float* o = a.out + (size_t)n * H + 4 * hh;
-#pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) v[m] = y[T][0][4 * q + m];
-                *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = v;
-            }
-    }
-}
-
-
-// ----------------------------------------------------------------------------------------------
-// Two-waves-per-SIMD edition of the split kernel.  A 512-thread workgroup = 4 node blocks x 2 CHANNEL HALVES:
-// wave (nbk = wave & 3, chh = wave >> 2) owns the output tiles {2 chh, 2 chh + 1} (64 of the 128 channels) of
-// node block nbk for every GEMM, so it keeps only half of each state / accumulator (y, z, g, acc: 4 x 32
-// registers) and fits 256 registers: two waves share a SIMD and one's activation VALU overlaps the other's
-// matrix work.  A GEMM needs all 128 k (channels) of the state as B operand: after every state update each wave
-// splits its two tiles into hi/lo fragments and publishes them in LDS ([node block][tile 4][step 2][plane 2][lane 64]
-// half8 = 16 KB per node block, one area for y and one for z); the GEMMs read their B fragments from there.
-// ----------------------------------------------------------------------------------------------
-struct WStage2 {
-    f32x4 r[2];
-};
-__device__ __forceinline__ void wstage2_load(WStage2& s, const float* __restrict__ chunk, int tid) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) s.r[i] = *reinterpret_cast<const f32x4*>(chunk + 4 * (tid + 512 * i));
-}
-__device__ __forceinline__ void wstage2_store(const WStage2& s, float* buf, int tid) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(buf + 4 * (tid + 512 * i)) = s.r[i];
-}
-
-// acc[i] += W_chunk[rows of tile tile0 + i] * B for the 32 k of one split chunk (two of the four row tiles)
-__device__ __forceinline__ void mma_chunk_split_half(const float* wl, int lane, int tile0, const half8 (&bhi)[2],
-                                                     const half8 (&blo)[2], f32x16 (&acc)[2]) {
-    const half8* w = reinterpret_cast<const half8*>(wl) + lane;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const half8 ahi = w[((s * 4 + tile0 + i) * 2 + 0) * 64];
-            const half8 alo = w[((s * 4 + tile0 + i) * 2 + 1) * 64];
-            MSMP_MFMA_LOLO(2, acc[i], alo, blo[s]);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[s], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[s], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[s], acc[i], 0, 0, 0);
-        }
-}
-
-// acc[i] = bias[row0 + 32 i + ..] (+ input columns as NS fp32 MFMA k-steps from the pre-scaled fragments)
-template <int NS>
-__device__ __forceinline__ void lem_acc_init_half(const float* bias_rows, const float* wf_tile0, int hh, const float (&x)[2 * NS],
-                                                  bool with_inputs, f32x16 (&acc)[2]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_rows + 32 * i + 8 * q + 4 * hh);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[i][4 * q + m] = bv[m];
-        }
-    if (with_inputs) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const float b = hh ? x[2 * s + 1] : x[2 * s];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf_tile0[(i * 4 + s) * 64], b, acc[i], 0, 0, 0);
-        }
-    }
-}
-
-// split this wave's two state tiles into hi/lo fragments and publish them in the node block's exchange area
-__device__ __forceinline__ void lem_publish(const f32x16 (&st)[2], half8* xb, int tile0, int lane) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = st[i][8 * s + j];
-            half8 hi, lo;
-            split8(v, hi, lo);
-            xb[(((tile0 + i) * 2 + s) * 2 + 0) * 64 + lane] = hi;
-            xb[(((tile0 + i) * 2 + s) * 2 + 1) * 64 + lane] = lo;
-        }
-    __syncthreads();
-}
-
-// B fragments of K tile kc (all 128 channels are published by the two waves of the node block)
-__device__ __forceinline__ void lem_frags(const half8* xb, int kc, int lane, half8 (&bhi)[2], half8 (&blo)[2]) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        bhi[s] = xb[((kc * 2 + s) * 2 + 0) * 64 + lane];
-        blo[s] = xb[((kc * 2 + s) * 2 + 1) * 64 + lane];
-    }
-}
-
-template <int NS>
-__global__ __launch_bounds__(512, 2) void lem_encoder_split2_kernel(LemSplitArgs sa) {
-    // weights 2 x 16 KB | y fragments 4 node blocks x 16 KB | z fragments 4 x 16 KB = 160 KB: one workgroup per CU
-    __shared__ __attribute__((aligned(16))) float lds[10 * SPLIT_CHUNK_FLOATS];
-    const LemArgs& a = sa.b;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nbk = wave & 3, chh = wave >> 2, tile0 = 2 * chh;
-    const int c = lane & 31, hh = lane >> 5;
-    const long n = (long)blockIdx.x * 128 + nbk * 32 + c;
-    const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
-    const float* xrow = a.xin + (size_t)nc * a.t_len * (2 * NS);
-    half8* xy = reinterpret_cast<half8*>(lds + 2 * SPLIT_CHUNK_FLOATS) + nbk * 1024;
-    half8* xz = reinterpret_cast<half8*>(lds + 6 * SPLIT_CHUNK_FLOATS) + nbk * 1024;
-    const float LOG2E = 1.44269504088896340736f;
-    const float cW = -sa.scales[4] * LOG2E, cW2 = -2.0f * sa.scales[4] * LOG2E, cZ2 = -2.0f * sa.scales[5] * LOG2E;
-
-    f32x16 y[2], z[2], g[2], acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { y[i][r] = 0.f; z[i][r] = 0.f; }
-
-    WStage2 ws;
-    wstage2_load(ws, a.rec, tid);
-    wstage2_store(ws, lds, tid);
-    lem_publish(y, xy, tile0, lane);           // y = 0 fragments (+ the barrier that also covers the weight chunk)
-
-#define LEM_GROUP_H(ACC, BASE, XB, NEXT_AFTER_LAST)                                                    \
-    _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) {                                                 \
-        const float* nxt = kc < 3 ? a.rec + (size_t)((BASE) + kc + 1) * SPLIT_CHUNK_FLOATS : (NEXT_AFTER_LAST); \
-        wstage2_load(ws, nxt, tid);                                                                    \
-        half8 bhi[2], blo[2];                                                                          \
-        lem_frags(XB, kc, lane, bhi, blo);                                                             \
-        mma_chunk_split_half(lds + (((BASE) + kc) & 1) * SPLIT_CHUNK_FLOATS, lane, tile0, bhi, blo, ACC); \
-        wstage2_store(ws, lds + (((BASE) + kc + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);                    \
-        __syncthreads();                                                                               \
-    }
-    // sigmoid(x 2^-s) = 1 / (1 + 2^(c x)),  tanh(x 2^-s) = sign(x) (1 - e) / (1 + e), e = 2^(c2 |x|)
-    auto sig = [](float x, float cc) { return msmp_rcp(1.0f + msmp_exp2(x * cc)); };
-    auto tnh = [](float x, float c2) {
-        const float e = msmp_exp2(fabsf(x) * c2);
-        return copysignf((1.0f - e) * msmp_rcp(1.0f + e), x);
-    };
-    const float* wfb = a.wx + lane + (size_t)tile0 * 4 * 64;
-
-    for (int t = 0; t < a.t_len; ++t) {
-        float x[2 * NS];
-#pragma unroll
-        for (int f = 0; f < 2 * NS; ++f) x[f] = xrow[t * (2 * NS) + f];
-        const float* after = t + 1 == a.t_len ? a.mlp : a.rec;
-
-        lem_acc_init_half<NS>(a.bias + H * 1 + 32 * tile0, wfb + 1 * 1024, hh, x, true, g);      // g2 -> dt_
-        LEM_GROUP_H(g, 0, xy, a.rec + 4 * SPLIT_CHUNK_FLOATS)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[i][r] = a.dt * sig(g[i][r], cW);
-        lem_acc_init_half<NS>(a.bias + H * 2 + 32 * tile0, wfb + 2 * 1024, hh, x, true, acc);    // g3 -> z
-        LEM_GROUP_H(acc, 4, xy, a.rec + 8 * SPLIT_CHUNK_FLOATS)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[i][r] = fmaf(g[i][r], tnh(acc[i][r], cW2) - z[i][r], z[i][r]);
-        lem_publish(z, xz, tile0, lane);                                                         // z fragments (lin reads them)
-        lem_acc_init_half<NS>(a.bias + H * 0 + 32 * tile0, wfb + 0 * 1024, hh, x, true, g);      // g1 -> dt_bar
-        LEM_GROUP_H(g, 8, xy, a.rec + 12 * SPLIT_CHUNK_FLOATS)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[i][r] = a.dt * sig(g[i][r], cW);
-        lem_acc_init_half<NS>(a.bias + H * 3 + 32 * tile0, wfb + 3 * 1024, hh, x, true, acc);    // lin -> y
-        LEM_GROUP_H(acc, 12, xz, after)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) y[i][r] = fmaf(g[i][r], tnh(acc[i][r], cZ2) - y[i][r], y[i][r]);
-        lem_publish(y, xy, tile0, lane);                                                         // y fragments for the next step
-    }
-
-    if (a.with_mlp) {
-        const float invA = sa.scales[6], invB = sa.scales[7];
-        float dummy[2 * NS];
-#pragma unroll
-        for (int f = 0; f < 2 * NS; ++f) dummy[f] = 0.f;
-        lem_acc_init_half<NS>(a.mlpb + 32 * tile0, nullptr, hh, dummy, false, acc);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            wstage2_load(ws, a.mlp + (size_t)(j + 1) * SPLIT_CHUNK_FLOATS, tid);
-            half8 bhi[2], blo[2];
-            lem_frags(xy, j, lane, bhi, blo);
-            mma_chunk_split_half(lds + (j & 1) * SPLIT_CHUNK_FLOATS, lane, tile0, bhi, blo, acc);
-            wstage2_store(ws, lds + ((j + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
-            __syncthreads();
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = swishf(acc[i][r] * invA);
-        lem_publish(acc, xz, tile0, lane);
-        lem_acc_init_half<NS>(a.mlpb + H + 32 * tile0, nullptr, hh, dummy, false, y);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j < 3) wstage2_load(ws, a.mlp + (size_t)(4 + j + 1) * SPLIT_CHUNK_FLOATS, tid);
-            half8 bhi[2], blo[2];
-            lem_frags(xz, j, lane, bhi, blo);
-            mma_chunk_split_half(lds + (j & 1) * SPLIT_CHUNK_FLOATS, lane, tile0, bhi, blo, y);
-            if (j < 3) {
-                wstage2_store(ws, lds + ((j + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
-                __syncthreads();
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) y[i][r] = swishf(y[i][r] * invB);
-    }
-#undef LEM_GROUP_H
-
-    if (n < a.n_nodes) {
-        float* o = a.out + (size_t)n * H + 32 * tile0 + 4 * hh;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) v[m] = y[i][4 * q + m];
-                *reinterpret_cast<f32x4*>(o + 32 * i + 8 * q) = v;
-            }
-    }
-}
-
-// ----------------------------------------------------------------------------------------------
 // WEIGHT-STATIONARY edition (default).  The recurrent weights (4 gates x [128 x 128], fp16 hi + lo = 256 KB) fit the
 // CU's register file: a 512-thread workgroup = 4 channel slices x 2 roles, and wave (ks, role) keeps the hi/lo A
 // fragments of TWO gate tiles (rows 32 ks .. 32 ks + 31; 128 registers) for the whole kernel:
@@ -1387,7 +1025,7 @@ extern "C" __attribute__((visibility("default"))) int msmp_debug_prof_lem(unsign
 }
 #endif
 int g_lem_nodes = 1;     // msmp_tune("lem_nodes", 0): msmp_lem_encoder_nodes_f32 declines, callers assemble the [N,T,ninp] tensor (A/B)
-int g_lem_split = 4;     // 4: weight-stationary anti-phased kernel (three node tiles), 3: weight-stationary two-tile kernel, 1: streamed-weight two-waves-per-SIMD split kernel, 2: one-wave split kernel,
+int g_lem_split = 4;     // 4: weight-stationary anti-phased kernel (three node tiles), 3: weight-stationary two-tile kernel (round 2),
                          // 0: fp32 MFMA (msmp_tune "lem"; "split" 1/0 selects 4/0)
 extern "C" int64_t msmp_packed_lem_floats(void) { return lem_layout().total; }
 
@@ -1448,26 +1086,6 @@ extern "C" int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len
             case 6: hipLaunchKernelGGL((lem_encoder_ws_kernel<6, 0>), dim3(g64), dim3(512), 0, st, wa); break;
             case 7: hipLaunchKernelGGL((lem_encoder_ws_kernel<7, 0>), dim3(g64), dim3(512), 0, st, wa); break;
             default: hipLaunchKernelGGL((lem_encoder_ws_kernel<8, 0>), dim3(g64), dim3(512), 0, st, wa); break;
-        }
-    } else if (g_lem_split == 1) {
-        LemSplitArgs sa{LemArgs{xin, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s, packed + L.mlp_s, packed + L.bias_s,
-                                packed + L.wx_s, packed + L.mlpb_s, h_out},
-                        packed + L.scales};
-        switch ((ninp + 1) / 2) {
-            case 1: hipLaunchKernelGGL(lem_encoder_split2_kernel<1>, dim3(grid), dim3(512), 0, (hipStream_t)stream, sa); break;
-            case 2: hipLaunchKernelGGL(lem_encoder_split2_kernel<2>, dim3(grid), dim3(512), 0, (hipStream_t)stream, sa); break;
-            case 3: hipLaunchKernelGGL(lem_encoder_split2_kernel<3>, dim3(grid), dim3(512), 0, (hipStream_t)stream, sa); break;
-            default: hipLaunchKernelGGL(lem_encoder_split2_kernel<4>, dim3(grid), dim3(512), 0, (hipStream_t)stream, sa); break;
-        }
-    } else if (g_lem_split) {
-        LemSplitArgs sa{LemArgs{xin, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s, packed + L.mlp_s, packed + L.bias_s,
-                                packed + L.wx_s, packed + L.mlpb_s, h_out},
-                        packed + L.scales};
-        switch ((ninp + 1) / 2) {
-            case 1: hipLaunchKernelGGL(lem_encoder_split_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sa); break;
-            case 2: hipLaunchKernelGGL(lem_encoder_split_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sa); break;
-            case 3: hipLaunchKernelGGL(lem_encoder_split_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sa); break;
-            default: hipLaunchKernelGGL(lem_encoder_split_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sa); break;
         }
     } else
     switch ((ninp + 1) / 2) {

@@ -391,7 +391,7 @@ def test_lem_encoder_kernel(mp, ninp, t_len, n):
         ys = lem.encode(xin, None)           # default: fp16-split matrix path, weight-stationary kernel
         hs = lem.encode(xin, mlp)
         older = {}
-        for variant in (1, 2, 3):           # streamed-weight split kernels (two waves / one wave per SIMD), two-tile weight-stationary kernel
+        for variant in (3,):                # the two-tile weight-stationary kernel of round 2 (the streamed-weight editions are gone)
             mp.lib().msmp_tune(b'lem', variant)
             older[variant] = (lem.encode(xin, None), lem.encode(xin, mlp))
         mp.lib().msmp_tune(b'split', 0)
@@ -544,9 +544,9 @@ def test_lem_encoder_in_kernel_input_assembly(mp, two_d, nv, tw, n):
         ref = lem.encode(xin.contiguous(), mlp)
         out = lem.encode_nodes(u, pos_x, pos_t, variables, dt, two_d, mlp)
         assert out is not None and torch.equal(out, ref)
-        mp.lib().msmp_tune(b'lem', 1)
+        mp.lib().msmp_tune(b'lem', 3)
         try:
-            assert lem.encode_nodes(u, pos_x, pos_t, variables, dt, two_d, mlp) is None      # only the default edition has it
+            assert torch.equal(lem.encode_nodes(u, pos_x, pos_t, variables, dt, two_d, mlp), lem.encode(xin.contiguous(), mlp))      # the two-tile edition too
         finally:
             mp.lib().msmp_tune(b'lem', 4)
 
