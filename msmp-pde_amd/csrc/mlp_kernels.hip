@@ -974,30 +974,43 @@ struct TailArgs {
 // One update head, update_net_2 transposed: yT[T][r] = 2^s4 (W4 Swish(W3 [h ; agg ; vars] + b3) + b4)[channel 4 c + T]
 // of node acc_row(r, hh) of the wave's 32-node tile (the w4t fragments deal the output channels round-robin over the
 // four tiles, so a lane owns four CONSECUTIVE channels and h / h' move as 16-byte pieces of 512-byte rows).
-// head_rows_issue starts the loads of the lane's slices of its h / agg rows for k-chunks 0..3 (the gated kernel issues
-// the main head's during the gate head's update_net_2); head_compute ends with the weight buffers free.
-struct HeadRows {
-    f32x4 pf[4][4];
-};
+// tail_rows_issue starts the LDS-DMA of the first 32-column chunk of the graph's rows (the gated kernel issues the main head's
+// during the gate head's update_net_2); head_compute ends with the weight buffers free.
 constexpr float TAIL_ACT_SCALE = 64.0f;       // hidden units of the update net (Swish outputs)
 constexpr float TAIL_NODE_SCALE = 256.0f;     // node rows (h, aggregate, variables): saturating, see tile_kernels.hip
 __device__ __forceinline__ float tail_node_scaled(float x) { return __builtin_amdgcn_fmed3f(x * TAIL_NODE_SCALE, -65504.0f, 65504.0f); }
-__device__ __forceinline__ void head_row_load(const float* __restrict__ h, const float* __restrict__ agg, long nc, int hh, int ch,
-                                              f32x4 (&dst)[4]) {
-    const float* row32 = (ch < 4 ? h : agg) + (size_t)nc * H + 32 * (ch & 3);
+
+// The graph's node rows reach the update GEMM through LDS, one 32-column chunk (128 rows x 128 B = 16 KB) at a time, filled by
+// LDS-DMA (global_load_lds_dwordx4: no registers, no VALU): a wave-instruction copies 8 whole 128-byte lines, so every line of h /
+// agg is fetched ONCE per head, coalesced.  Round 2 loaded the B fragments straight into registers, a row per lane: every
+// instruction touched 32 different lines and every line was touched by four instructions (rocprofv3: 41 % of the wave cycles
+// waiting on memory; replacing the row gather by a broadcast load removed 16 % of the kernel).  The 16-byte pieces of a row
+// are XOR-swizzled on the SOURCE address (the LDS image of an LDS-DMA is lane-linear), so that the ds_read_b128 of a 16-lane
+// group (16 rows, the same piece) hits 16 different 4-bank groups: piece p of row r sits in slot p ^ ((r >> 1) & 7).
+constexpr int ROWBUF_FLOATS = 128 * 32;
+__device__ __forceinline__ void tail_rows_issue(const float* __restrict__ h, const float* __restrict__ agg, int n0, int n1, int ch, float* buf, int tid) {
+    const float* src = (ch < 4 ? h : agg) + 32 * (ch & 3);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        dst[2 * s] = *reinterpret_cast<const f32x4*>(row32 + 16 * s + 8 * hh);
-        dst[2 * s + 1] = *reinterpret_cast<const f32x4*>(row32 + 16 * s + 8 * hh + 4);
+    for (int i = 0; i < 4; ++i) {
+        const int P = tid + 256 * i, r = P >> 3;
+        const int node = min(n0 + r, n1 - 1);
+        const float* g = src + (size_t)node * H + 4 * ((P & 7) ^ ((r >> 1) & 7));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(buf + 4 * P), 16, 0, 0);
     }
 }
-__device__ __forceinline__ void head_rows_issue(const float* __restrict__ h, const float* __restrict__ agg, long nc, int hh, HeadRows& st) {
+// this lane's 16 values of its row for the staged chunk: k = 16 s + 8 hh + 0..7
+__device__ __forceinline__ void tail_rows_read(const float* buf, int row, int hh, f32x4 (&dst)[4]) {
+    const float* rb = buf + row * 32;
+    const int sw = (row >> 1) & 7;
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) head_row_load(h, agg, nc, hh, ch, st.pf[ch]);
+    for (int s = 0; s < 2; ++s) {
+        dst[2 * s] = *reinterpret_cast<const f32x4*>(rb + 4 * ((4 * s + 2 * hh) ^ sw));
+        dst[2 * s + 1] = *reinterpret_cast<const f32x4*>(rb + 4 * ((4 * s + 2 * hh + 1) ^ sw));
+    }
 }
 
 template <typename MidHook>
-__device__ __forceinline__ void head_compute(HeadRows& st, const float* __restrict__ h, const float* __restrict__ agg,
+__device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, const float* __restrict__ h, const float* __restrict__ agg,
                                              const float* __restrict__ vars, long nc, int nv, const float* b3, const float* b4,
                                              const float* w3vh, const float* w3s, const float* w4t, const float* scales, float* lds,
                                              int tid, int lane, int c, int hh, f32x16 (&yT)[4], MidHook mid_hook, bool center, float* zref PROF_ARGS) {
@@ -1011,20 +1024,25 @@ __device__ __forceinline__ void head_compute(HeadRows& st, const float* __restri
     f32x16 z[4][1];
     acc_init_bias_scaled<1>(b3, sc3, hh, z);
     wstage_store_linear(ws, lds, tid);
-    __syncthreads();
+    __syncthreads();                // (with the vmcnt(0) of the LDS-DMA in flight: chunk 0 of the rows has landed)
     PROF_MARK(5);
+    const int myrow = (tid >> 6) * 32 + c;
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
+        if (ch < 7) tail_rows_issue(h, agg, n0, n1, ch + 1, rowbuf + ((ch + 1) & 1) * ROWBUF_FLOATS, tid);
         wstage_load(ws, ch < 7 ? w3s + (size_t)(ch + 1) * SPLIT_CHUNK_FLOATS : w4t, tid);
         half8 bhi[1][2], blo[1][2];
+        {
+            f32x4 pf[4];
+            tail_rows_read(rowbuf + (ch & 1) * ROWBUF_FLOATS, myrow, hh, pf);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const f32x4 v0 = st.pf[ch & 3][2 * s], v1 = st.pf[ch & 3][2 * s + 1];
-            const float v[8] = {tail_node_scaled(v0[0]), tail_node_scaled(v0[1]), tail_node_scaled(v0[2]), tail_node_scaled(v0[3]),
-                                tail_node_scaled(v1[0]), tail_node_scaled(v1[1]), tail_node_scaled(v1[2]), tail_node_scaled(v1[3])};
-            split8(v, bhi[0][s], blo[0][s]);
+            for (int s = 0; s < 2; ++s) {
+                const f32x4 v0 = pf[2 * s], v1 = pf[2 * s + 1];
+                const float v[8] = {tail_node_scaled(v0[0]), tail_node_scaled(v0[1]), tail_node_scaled(v0[2]), tail_node_scaled(v0[3]),
+                                    tail_node_scaled(v1[0]), tail_node_scaled(v1[1]), tail_node_scaled(v1[2]), tail_node_scaled(v1[3])};
+                split8(v, bhi[0][s], blo[0][s]);
+            }
         }
-        if (ch + 4 < 8) head_row_load(h, agg, nc, hh, ch + 4, st.pf[ch & 3]);
         if (ch == 5) {      // the variables and their slot fragments are consumed after the k loop: issued two chunks ahead
 #pragma unroll
             for (int f = 0; f < 8; ++f) xv[f] = f < nv ? tail_node_scaled(vars[(size_t)nc * nv + f]) : 0.f;
@@ -1188,6 +1206,7 @@ __device__ __forceinline__ void tile_t_instance_norm(f32x16 (&x)[4], int wave, i
 template <bool GATED>
 __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS];
+    __shared__ __attribute__((aligned(16))) float rowbuf[2 * ROWBUF_FLOATS];        // two staged 32-column chunks of the graph's node rows
     __shared__ float part[8 * H];
     __shared__ float tot[H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1199,12 +1218,11 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
     const long nc = n < n1 ? n : n1 - 1;
 
     PROF_DECL
-    HeadRows rows;
     f32x16 tau[4];
     if (GATED) {
-        head_rows_issue(a.h, a.agg[1], nc, hh, rows);
-        head_compute(rows, a.h, a.agg[1], a.vars, nc, a.nv, a.b3[1], a.b4[1], a.w3vh[1], a.w3s[1], a.w4t[1], a.scales[1], lds, tid, lane,
-                     c, hh, tau, [&] { head_rows_issue(a.h, a.agg[0], nc, hh, rows); }, true, tot PROF_PASS);
+        tail_rows_issue(a.h, a.agg[1], n0, n1, 0, rowbuf, tid);
+        head_compute(rowbuf, n0, n1, a.h, a.agg[1], a.vars, nc, a.nv, a.b3[1], a.b4[1], a.w3vh[1], a.w3s[1], a.w4t[1], a.scales[1], lds, tid, lane,
+                     c, hh, tau, [&] { tail_rows_issue(a.h, a.agg[0], n0, n1, 0, rowbuf, tid); }, true, tot PROF_PASS);
         PROF_MARK(0);
         tile_t_instance_norm(tau, wave, cnt, a.scales[1][7] * (1.0f / TAIL_ACT_SCALE), a.eps, part, tot, tid, c, hh, a.status);
 #pragma unroll
@@ -1213,10 +1231,10 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
             for (int r = 0; r < 16; ++r) tau[T][r] = sigmoidf_(tau[T][r]);
         PROF_MARK(1);
     } else {
-        head_rows_issue(a.h, a.agg[0], nc, hh, rows);
+        tail_rows_issue(a.h, a.agg[0], n0, n1, 0, rowbuf, tid);
     }
     f32x16 y[4];
-    head_compute(rows, a.h, a.agg[0], a.vars, nc, a.nv, a.b3[0], a.b4[0], a.w3vh[0], a.w3s[0], a.w4t[0], a.scales[0], lds, tid, lane, c, hh,
+    head_compute(rowbuf, n0, n1, a.h, a.agg[0], a.vars, nc, a.nv, a.b3[0], a.b4[0], a.w3vh[0], a.w3s[0], a.w4t[0], a.scales[0], lds, tid, lane, c, hh,
                  y, [] {}, GATED || a.mode == MSMP_LAYER_LIN, tot PROF_PASS);
     PROF_MARK(2);
     // this lane's piece of the transposed tiles: nodes n0 + 32 wave + acc_row(r, hh), channels 4 c .. 4 c + 3 (tile T = channel 4 c + T)
