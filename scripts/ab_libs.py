@@ -1,9 +1,9 @@
 """A/B of two builds of the library on the default bench workload in ONE gpurun call (separate processes, interleaved):
-    python scripts/ab_libs.py libA.so libB.so [rounds]"""
+    python scripts/ab_libs.py libA.so libB.so [libC.so ...] [rounds]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-libs = sys.argv[1:3]
-rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+libs = [a for a in sys.argv[1:] if not a.isdigit()]
+rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
