@@ -295,14 +295,17 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
     // this wave's targets [gf, gl) and, for lane c < gl - gf, the lanes [er0, er0 + edeg) of this wave that hold target gf + c's in-edges
     // (consumed by the mean at the very end: requested here, off the critical path)
     const int gf = min(tile_n0 + wave * a.group_nodes, tile_n1), gl = min(gf + a.group_nodes, tile_n1);
+    // (unconditional loads at a clamped index, the arithmetic deferred to the epilogue: inside a lane-masked block the compiler waits
+    // for the loads on the spot -- a memory round trip at the head of every tile's dependent chain)
+    const int rp_base = a.rowptr[__builtin_amdgcn_readfirstlane(gf)];      // wave-uniform: a scalar load
+    const int rp_row = gf + min(c, max(gl - gf - 1, 0));
+    int rp_lo = a.rowptr[rp_row], rp_hi = a.rowptr[rp_row + 1];
     int er0 = 0, edeg = 0;
-    {
-        const int ebase = a.rowptr[gf];
-        if (c < gl - gf) {
-            er0 = a.rowptr[gf + c] - ebase;
-            edeg = a.rowptr[gf + c + 1] - ebase - er0;
-        }
-    }
+    auto edge_ranges = [&]() {           // called once the stage's own loads are out (and about to be waited for anyway)
+        asm volatile("" : "+v"(rp_lo), "+v"(rp_hi));
+        er0 = rp_lo - rp_base;
+        edeg = c < gl - gf ? rp_hi - rp_lo : 0;
+    };
     // nibble -> four fp16 values 0 / 1: the building block of the mean's selection matrix (read after many barriers)
     if (tid < 16) {
         unsigned* lut = reinterpret_cast<unsigned*>(lds + TILE_MAIN_FLOATS);
@@ -325,6 +328,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
             pv[i] = *reinterpret_cast<const f32x4*>(a.P + (size_t)node * H + 4 * piece) * ACT_SCALE;
             qv[i] = *reinterpret_cast<const f32x4*>(a.Q + (size_t)node * H + 4 * piece) * ACT_SCALE;
         }
+        edge_ranges();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int slot = (tid >> 5) + 8 * i;
@@ -407,6 +411,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
                         }
                     }
             }
+            edge_ranges();
             {       // range sentinel: node_scaled saturates silently (v_max3 drops NaN: a NaN row was flagged where it was produced)
                 float mx = 0.f;
 #pragma unroll
