@@ -395,6 +395,23 @@ int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, const float* u,
 int msmp_adamw_f32(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int64_t step, msmp_stream_t stream);
+/* The same step for a captured training iteration (a hipGraph replays fixed kernel arguments): the step count lives in device
+ * memory (step_dev[0], int64, advanced by this call) and so does the learning rate (lr_dev[0]; a scheduler's new value is a
+ * host-to-device copy between replays).  Bias corrections are computed on the device from step_dev. */
+int msmp_adamw_capturable_f32(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                              float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, float beta1, float beta2,
+                              float eps, float weight_decay, int64_t* step_dev, msmp_stream_t stream);
+
+/* Deterministic reductions for the PyTorch-side pieces of a training iteration (bias gradients of the encoder / decoder, the
+ * loss of experiments/train_helper.py:125-141): fixed summation order, two kernel launches, no atomics, no memset -- safe inside a
+ * captured (hipGraph) training step.  workspace >= msmp_reduce_workspace_bytes(cols) (cols = 1 for the scalar sum).
+ *   msmp_colsum_f32:    out[j] = sum over rows r and columns c in [j group, (j + 1) group) of x[r][c]   (x [rows, cols] row-major)
+ *   msmp_sqerr_sum_f32: out[0] = sum_i (a[i] - b[i])^2 */
+size_t msmp_reduce_workspace_bytes(int cols);
+int msmp_colsum_f32(const float* x, int64_t rows, int cols, int group, float* out, void* workspace, size_t workspace_bytes,
+                    msmp_stream_t stream);
+int msmp_sqerr_sum_f32(const float* a, const float* b, int64_t n, float* out, void* workspace, size_t workspace_bytes,
+                       msmp_stream_t stream);
 
 /* The per-edge input of message_net_1 (models_gnn.py:69-75): out[e] = cat(h[i], h[j], u[i]-u[j], pos[i]-pos[j], vars[i]),
  * i = tgt[e], j = col[e]; out [E, ld] with ld >= 256 + tw + 1 + nv a multiple of 4 (columns past the concat are not written). */

@@ -80,6 +80,10 @@ SIGNATURES = {
     'msmp_mp_layer_bwd_f32': (c_int, [c_void_p] * 11 + [c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'msmp_adamw_f32': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int64, c_void_p]),
+    'msmp_adamw_capturable_f32': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+    'msmp_reduce_workspace_bytes': (c_size_t, [c_int]),
+    'msmp_colsum_f32': (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'msmp_sqerr_sum_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     'msmp_packed_mlp2_floats': (c_int64, [c_int]),
     'msmp_mlp2_input_stride': (c_int, [c_int]),
     'msmp_pack_mlp2_f32': (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_void_p]),

@@ -1326,6 +1326,88 @@ extern "C" int msmp_mp_layer_bwd_f32(const float* grad_out, const float* h, cons
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Deterministic reductions for the pieces of a training iteration that stay in PyTorch (encoder / decoder bias gradients, the loss
+// sum, experiments/train_helper.py:125-141): two launches each, partial sums in a caller's workspace, fixed order, no atomics and
+// no zero-initialised semaphore -- a library reduction's hipMemsetAsync becomes a memset NODE in a captured training step and was
+// seen to replay out of order.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace msmp {
+constexpr int RED_BLOCKS = 128;
+// partial[b][c] = sum of x[r][c] over the rows of block b
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long rows, int cols, float* __restrict__ partial) {
+    const long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * per, r1 = min(r0 + per, rows);
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float s = 0.f;
+        for (long r = r0; r < r1; ++r) s += x[(size_t)r * cols + c];
+        partial[(size_t)blockIdx.x * cols + c] = s;
+    }
+}
+__device__ __forceinline__ float block_sum_256(float v, float* red) {       // fixed tree, every thread returns the total
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+// out[j] = sum over blocks and over the `group` consecutive columns of output j: one workgroup per output, element (b, g) of the
+// blocks x group set at thread (b group + g) % 256 -- fixed order, then the fixed tree
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int blocks, int cols, int group, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int j = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < blocks * group; i += 256) s += partial[(size_t)(i / group) * cols + j * group + i % group];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[j] = s;
+}
+__global__ __launch_bounds__(256) void sqerr_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ partial) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = a[i] - b[i];
+        s = fmaf(d, d, s);
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sum_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+}  // namespace msmp
+
+extern "C" size_t msmp_reduce_workspace_bytes(int cols) { return (size_t)RED_BLOCKS * (size_t)(cols > 1 ? cols : 1) * sizeof(float); }
+
+extern "C" int msmp_colsum_f32(const float* x, int64_t rows, int cols, int group, float* out, void* workspace, size_t workspace_bytes,
+                               msmp_stream_t stream) {
+    MSMP_REQUIRE(x && out && workspace, MSMP_ERR_ARG, "msmp_colsum_f32: null pointer");
+    MSMP_REQUIRE(rows >= 0 && cols >= 1 && group >= 1 && cols % group == 0, MSMP_ERR_ARG, "msmp_colsum_f32: bad sizes");
+    MSMP_REQUIRE(workspace_bytes >= msmp_reduce_workspace_bytes(cols), MSMP_ERR_WORKSPACE, "msmp_colsum_f32: workspace %zu < %zu", workspace_bytes,
+                 msmp_reduce_workspace_bytes(cols));
+    const int blocks = (int)(rows < RED_BLOCKS ? (rows > 0 ? rows : 1) : RED_BLOCKS);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)rows, cols, (float*)workspace);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)(cols / group)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, blocks,
+                       cols, group, out);
+    return check_launch("colsum_kernel");
+}
+
+extern "C" int msmp_sqerr_sum_f32(const float* a, const float* b, int64_t n, float* out, void* workspace, size_t workspace_bytes,
+                                  msmp_stream_t stream) {
+    MSMP_REQUIRE(a && b && out && workspace, MSMP_ERR_ARG, "msmp_sqerr_sum_f32: null pointer");
+    MSMP_REQUIRE(n >= 0 && workspace_bytes >= msmp_reduce_workspace_bytes(1), MSMP_ERR_ARG, "msmp_sqerr_sum_f32: bad sizes / workspace");
+    hipLaunchKernelGGL(sqerr_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, (float*)workspace);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, RED_BLOCKS, out);
+    return check_launch("sqerr_sum_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Fused AdamW (experiments/train.py:410: optim.AdamW(model.parameters(), lr)): every parameter tensor of the model in one or two
 // launches.  A launch carries up to ADAMW_MAX_TENSORS tensor descriptors in its kernel arguments; block b works on chunk
 // (b - first_block[t]) of tensor t.  Decoupled weight decay, bias-corrected moments, the same order of operations as
@@ -1343,8 +1425,17 @@ struct AdamWArgs {
     int first_block[ADAMW_MAX_TENSORS + 1];
     int n;
     float lr, beta1, beta2, eps, decay, bc1_inv, bc2_rsqrt;      // decay = 1 - lr wd;  bc1_inv = 1 / (1 - b1^t);  bc2_rsqrt = 1 / sqrt(1 - b2^t)
+    // capturable form (a hipGraph replays the same kernel arguments): step count and learning rate are read from device memory
+    const long long* step_dev;
+    const float* lr_dev;
+    float weight_decay;
 };
 
+__global__ void adamw_advance_kernel(long long* step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1;
+}
+
+template <bool DEV>
 __global__ __launch_bounds__(256) void adamw_kernel(AdamWArgs a) {
     int t = 0;
     while (t + 1 < a.n && (int)blockIdx.x >= a.first_block[t + 1]) ++t;
@@ -1354,6 +1445,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamWArgs a) {
     const float* __restrict__ g = a.g[t];
     float* __restrict__ m = a.m[t];
     float* __restrict__ v = a.v[t];
+    if (DEV) {          // the host entry's arithmetic, per block (two pow calls: nothing beside 4096 elements)
+        const double st = (double)a.step_dev[0];
+        a.lr = a.lr_dev[0];
+        a.decay = 1.0f - a.lr * a.weight_decay;
+        a.bc1_inv = (float)(1.0 / (1.0 - pow((double)a.beta1, st)));
+        a.bc2_rsqrt = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, st)));
+    }
     const float step = a.lr * a.bc1_inv;
 #pragma unroll
     for (int k = 0; k < ADAMW_CHUNK / 256; ++k) {
@@ -1370,11 +1468,30 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamWArgs a) {
 }
 }  // namespace msmp
 
+static int adamw_launch(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int64_t step, int64_t* step_dev, const float* lr_dev, msmp_stream_t stream);
+
 extern "C" int msmp_adamw_f32(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                               float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
                               float weight_decay, int64_t step, msmp_stream_t stream) {
+    MSMP_REQUIRE(step >= 1, MSMP_ERR_ARG, "msmp_adamw_f32: bad hyper-parameters");
+    return adamw_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, step, nullptr, nullptr, stream);
+}
+
+extern "C" int msmp_adamw_capturable_f32(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                                         float* const* exp_avg_sq, const int64_t* numel, const float* lr_dev, float beta1, float beta2,
+                                         float eps, float weight_decay, int64_t* step_dev, msmp_stream_t stream) {
+    MSMP_REQUIRE(lr_dev && step_dev, MSMP_ERR_ARG, "msmp_adamw_capturable_f32: null pointer");
+    hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)step_dev);
+    return adamw_launch(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, 0.f, beta1, beta2, eps, weight_decay, 1, step_dev, lr_dev, stream);
+}
+
+static int adamw_launch(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int64_t step, int64_t* step_dev, const float* lr_dev, msmp_stream_t stream) {
     MSMP_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (params && grads && exp_avg && exp_avg_sq && numel)), MSMP_ERR_ARG, "msmp_adamw_f32: null pointer");
-    MSMP_REQUIRE(step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, MSMP_ERR_ARG, "msmp_adamw_f32: bad hyper-parameters");
+    MSMP_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, MSMP_ERR_ARG, "msmp_adamw_f32: bad hyper-parameters");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     for (int t0 = 0; t0 < n_tensors; t0 += ADAMW_MAX_TENSORS) {
         AdamWArgs a;
@@ -1391,7 +1508,9 @@ extern "C" int msmp_adamw_f32(int n_tensors, float* const* params, const float* 
         a.first_block[a.n] = blocks;
         a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.decay = 1.0f - lr * weight_decay;
         a.bc1_inv = (float)(1.0 / bc1); a.bc2_rsqrt = (float)(1.0 / sqrt(bc2));
-        if (blocks) hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        a.step_dev = (const long long*)step_dev; a.lr_dev = lr_dev; a.weight_decay = weight_decay;
+        if (blocks && step_dev) hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        else if (blocks) hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     }
     return check_launch("adamw_kernel");
 }

@@ -25,12 +25,24 @@ from ._lib import lib, check, ptr, current_stream, PARAM_EPOCH
 from .graph import structure_of
 from .layers import GNN_Layer, GNN_LayerLin, Swish, mp_layer, node_features
 from .lem import LEM, LEMS
+from .reductions import bias_add
 
 _DECODER = {20: (15, 4, 10), 25: (16, 3, 14), 50: (12, 2, 10)}   # models_gnn.py:210-224; models_gnn2D.py:79-88
 
 
+class _Linear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose bias gradient is a deterministic column sum on the library's own kernel
+    (reductions.bias_add): the encoder's and decoder's Linear layers then put no library reduction into a captured training step."""
+
+    def forward(self, x):
+        if self.bias is None or not (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and self.bias.requires_grad):
+            return super().forward(x)
+        y = torch.nn.functional.linear(x, self.weight)
+        return bias_add(y.reshape(-1, y.shape[-1]), self.bias).view(y.shape)
+
+
 def _lin(i, o):
-    return nn.Linear(i, o, dtype=torch.float32)
+    return _Linear(i, o, dtype=torch.float32)
 
 
 _TOEPLITZ = {}
@@ -56,7 +68,7 @@ def _conv1d_as_matmul(x, weight, bias, stride):
         _TOEPLITZ[key] = (i == stride * l + tap).to(weight.dtype).reshape(k, lin * lout)
     t = (weight.reshape(cout * cin, k) @ _TOEPLITZ[key]).view(cout, cin, lin, lout).permute(1, 2, 0, 3).reshape(cin * lin, cout * lout)
     out = x.reshape(n, cin * lin) @ t
-    return out.view(n, cout, lout) + bias[None, :, None]
+    return bias_add(out, bias, lout).view(n, cout, lout)
 
 
 def _decoder_autograd(x, conv1, conv2):

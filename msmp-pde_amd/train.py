@@ -10,6 +10,8 @@ RCCL over xGMI when the backend is nccl.  Parameters are replicated; every rank 
 import torch
 import torch.distributed as dist
 
+from .reductions import sqerr_sum
+
 
 def _world():
     """Number of ranks; 0 when there is no process group at all (an initialised ONE-rank group still runs its collectives:
@@ -35,7 +37,7 @@ def dp_loss_backward(model, graph):
     """Forward + backward of the reference's loss on this rank's shard; gradients are left all-reduced
     (identical on every rank and equal to the single-device gradient).  Returns the global loss sqrt(S)."""
     pred = model(graph)
-    s_local = ((pred - graph.y.to(pred.dtype)) ** 2).sum()
+    s_local = sqerr_sum(pred, graph.y)                      # MSELoss(reduction='sum'), deterministic two-launch kernel on the GPU
     s_total = s_local.detach().clone()
     if _world() > 0:
         dist.all_reduce(s_total, op=dist.ReduceOp.SUM)
@@ -45,9 +47,12 @@ def dp_loss_backward(model, graph):
     return loss
 
 
-def training_step(model, creator, u_super, x, variables, random_steps, unrolled_graphs, optimizer):
-    """One iteration of training_loop (experiments/train_helper.py:91-141) on this rank's samples."""
-    optimizer.zero_grad()
+def training_step(model, creator, u_super, x, variables, random_steps, unrolled_graphs, optimizer, captured=None):
+    """One iteration of training_loop (experiments/train_helper.py:91-141) on this rank's samples.
+    captured: a CapturedTrainStep built on a batch of the same structure (same grid, batch size and neighbourhood): forward + loss +
+    backward + optimizer update are then ONE hipGraph launch; the pushforward unrolling stays eager (inference kernels)."""
+    if captured is None:
+        optimizer.zero_grad()
     steps = list(random_steps)
     data, labels = creator.create_data(u_super, steps)
     graph = creator.create_graph(data, labels, x, variables, steps)
@@ -57,9 +62,86 @@ def training_step(model, creator, u_super, x, variables, random_steps, unrolled_
             _, labels = creator.create_data(u_super, steps)
             pred = model(graph)
             graph = creator.create_next_graph(graph, pred, labels, steps)
-    loss = dp_loss_backward(model, graph)
-    optimizer.step()
+    if captured is not None:
+        loss = captured(graph)
+    else:
+        loss = dp_loss_backward(model, graph)
+        optimizer.step()
     lem = getattr(model, 'embedding_lem', None)            # the Save variants start every sample from fresh LEM states (:144-145)
     if hasattr(lem, 'reset_states'):
         lem.reset_states()
     return loss
+
+
+class CapturedTrainStep:
+    """hipGraph of ONE optimisation step on a fixed batch structure: forward, loss, backward and the optimizer update
+    (`dp_loss_backward` + `optimizer.step()`, experiments/train_helper.py:125-141) replayed as a single graph launch.
+
+    The reference's batch of 16 graphs is ~500 kernel launches of a few microseconds each: eager, the iteration is bound by
+    the host issuing them.  What makes the capture safe here:
+      * every kernel of the step is stream-ordered and takes no host read-back: layers / LEM forward and backward are the library's
+        kernels, the bias gradients of the encoder / decoder and the loss sum are its deterministic reductions (reductions.py: no
+        library reduction, hence no memset node in the graph), AdamW runs with the step count and learning rate in device memory
+        (optim.AdamW(capturable=True));
+      * everything the captured launches point at is owned here: static copies of the batch tensors, private layer / backward
+        workspaces, the gradients and the packed weight blobs (allocated from the graph's pool during capture);
+      * the weights are re-packed INSIDE the graph (the packed-blob caches are invalidated right before the capture, so every
+        replay packs the parameters it is about to use) and the caches are invalidated again after each replay, so an eager
+        forward in between (validation) packs the updated parameters.
+    The batch STRUCTURE (edge_index, batch vector, node count) is that of `graph` at construction; `__call__(graph)` copies the
+    floating-point node tensors (x, y, pos, equation-parameter columns) of another batch of the same structure and replays.
+    Single-process (no gradient all-reduce inside the graph)."""
+
+    def __init__(self, model, optimizer, graph, warmup=3):
+        import copy
+        from . import autograd as _ag
+        from .layers import _Workspace
+        from ._lib import invalidate_packed_weights
+        if _world() > 1:
+            raise RuntimeError('CapturedTrainStep: single-process only (the gradient all-reduce is not captured)')
+        if not all(g.get('capturable') for g in optimizer.param_groups):
+            raise RuntimeError('CapturedTrainStep needs msmp_pde_amd.optim.AdamW(..., capturable=True)')
+        self.model, self.opt = model, optimizer
+        self.data = copy.copy(graph)
+        self._float_keys = [k for k in graph.keys() if torch.is_tensor(getattr(graph, k)) and getattr(graph, k).is_floating_point()]
+        for k in self._float_keys:
+            setattr(self.data, k, getattr(graph, k).clone())
+        dev = self.data.x.device
+        self._invalidate = invalidate_packed_weights
+        old_bwd = _ag._bwd_ws.pop(dev, None)              # the backward's grow-only scratch: a private one for the graph
+        try:
+            with _Workspace.private(dev) as ws:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):             # eager warm-up: optimizer state, workspaces, structure caches
+                    for _ in range(warmup):
+                        optimizer.zero_grad(set_to_none=True)
+                        dp_loss_backward(model, self.data)
+                        optimizer.step()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                optimizer.zero_grad(set_to_none=True)
+                invalidate_packed_weights()               # the pack kernels must be part of the graph
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.loss = dp_loss_backward(model, self.data)
+                    optimizer.step()
+            self._ws = ws.buffers()
+            self._bwd_ws = _ag._bwd_ws.pop(dev, None)     # pinned: the captured backward points into it
+        finally:
+            if old_bwd is not None:
+                _ag._bwd_ws[dev] = old_bwd
+        self._blobs = [getattr(m, a) for m in model.modules() for a in ('_packed', '_embed_blob') if getattr(m, a, None) is not None]
+        self._params = [(p, p.data_ptr()) for p in model.parameters()]
+        invalidate_packed_weights()                       # the capture-time hook saw no replay: eager users re-pack
+
+    def __call__(self, graph):
+        for p, ptr0 in self._params:
+            if p.data_ptr() != ptr0:
+                raise RuntimeError('CapturedTrainStep: a parameter was re-allocated (model.to(), load_state_dict with assign): capture again')
+        for k in self._float_keys:
+            getattr(self.data, k).copy_(getattr(graph, k))
+        self.opt.sync_lr()                                # a scheduler may have changed param_groups[i]["lr"]
+        self.graph.replay()
+        self._invalidate()
+        return self.loss.clone()

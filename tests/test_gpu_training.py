@@ -167,6 +167,13 @@ def test_training_step_runs_and_decreases_loss(mp):
     losses = [T.training_step(model, c.creator, c.u_super, c.x, c.variables, [60] * 8, 1, opt).item() for _ in range(6)]
     print('losses', [round(l, 4) for l in losses])
     assert losses[-1] < losses[0]
+    # the same loop with the optimisation step as one hipGraph launch (pushforward forwards eager, reading the replayed updates)
+    opt2 = mp.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)
+    data, labels = c.creator.create_data(c.u_super, [60] * 8)
+    step = T.CapturedTrainStep(model, opt2, c.creator.create_graph(data, labels, c.x, c.variables, [60] * 8))
+    more = [T.training_step(model, c.creator, c.u_super, c.x, c.variables, [60] * 8, 1, opt2, captured=step).item() for _ in range(6)]
+    print('captured', [round(l, 4) for l in more])
+    assert more[-1] < more[0] < losses[0]
 
 
 @pytest.mark.parametrize('ninp,n,t_len', [(3, 77, 25), (4, 300, 25), (6, 129, 50), (8, 40, 7), (1, 33, 3)])
@@ -534,3 +541,109 @@ def test_fused_adamw_matches_torch(mp):
     od.step()
     torch.cuda.synchronize()
     assert float(od.state[w[0]]['step']) == 2.0 and float(od.state[w[1]]['step']) == 1.0
+
+
+def test_deterministic_reduction_kernels(mp):
+    """msmp_colsum_f32 / msmp_sqerr_sum_f32 (the bias gradients and the loss of a captured training step) against float64, and
+    bit-identical from run to run; the autograd wrappers route the encoder's Linear and the decoder's Conv1d bias gradients."""
+    from msmp_pde_amd import reductions as R
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    for rows, cols, group in ((1, 128, 1), (1600, 128, 1), (40000, 304, 38), (77, 25, 25), (5, 4096, 1)):
+        x = torch.randn(rows, cols, device='cuda', generator=gen)
+        got = R.colsum(x, group)
+        ref = x.double().view(rows, cols // group, group).sum((0, 2))
+        assert (got.double() - ref).abs().max().item() <= 2e-6 * (x.abs().double().view(rows, cols // group, group).sum((0, 2)).max().item() + 1e-30)
+        assert torch.equal(got, R.colsum(x, group))
+    a, b = torch.randn(1600, 25, device='cuda', generator=gen, requires_grad=True), torch.randn(1600, 25, device='cuda', generator=gen)
+    s = R.sqerr_sum(a, b)
+    ref = ((a.detach().double() - b.double()) ** 2).sum()
+    assert abs(s.item() - ref.item()) <= 1e-6 * ref.item() and torch.equal(s, R.sqerr_sum(a, b))
+    s.backward()
+    assert torch.equal(a.grad, 2.0 * (a.detach() - b))
+    lin = mp.solvers._lin(36, 128).cuda()
+    x = torch.randn(300, 36, device='cuda', generator=gen)
+    y = lin(x)
+    assert torch.allclose(y, torch.nn.functional.linear(x, lin.weight, lin.bias), rtol=0, atol=1e-6)
+    y.square().sum().backward()
+    gb = (2.0 * y.detach().double()).sum(0)
+    assert (lin.bias.grad.double() - gb).abs().max().item() <= 1e-5 * gb.abs().max().item()
+
+
+def test_capturable_adamw_matches_the_host_step_count_form(mp):
+    """optim.AdamW(capturable=True): step count and learning rate in device memory (msmp_adamw_capturable_f32) give the trajectory
+    of the default form, a scheduler's learning-rate change included; state_dict carries the device count back per parameter."""
+    torch.manual_seed(3)
+    wa = [torch.nn.Parameter(torch.randn(n, device='cuda')) for n in (1, 5000, 12345)]
+    wb = [torch.nn.Parameter(w.detach().clone()) for w in wa]
+    oa, ob = mp.optim.AdamW(wa, lr=1e-2), mp.optim.AdamW(wb, lr=1e-2, capturable=True)
+    sa = torch.optim.lr_scheduler.MultiStepLR(oa, milestones=[3], gamma=0.1)
+    sb = torch.optim.lr_scheduler.MultiStepLR(ob, milestones=[3], gamma=0.1)
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    for it in range(6):
+        for pa, pb in zip(wa, wb):
+            g = torch.randn(pa.shape, device='cuda', generator=gen)
+            pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step(); ob.step(); sa.step(); sb.step()
+        for pa, pb in zip(wa, wb):
+            assert (pa - pb).abs().max().item() <= 1e-6 * max(1.0, pa.abs().max().item()), it
+    sd = ob.state_dict()
+    assert all(float(sd['state'][i]['step']) == 6.0 for i in range(3)) and '_msmp_dev' not in sd['param_groups'][0]
+
+
+@pytest.mark.parametrize('name', ['MSMP-PDE', 'MP-PDE'])
+def test_captured_training_step_follows_the_eager_trajectory(mp, name):
+    """train.CapturedTrainStep (forward + loss + backward + AdamW of the reference's batch of 16 as ONE hipGraph launch) against the
+    same iterations run eagerly: bit-identical losses and parameters over changing batches, with eager inference forwards of the
+    model interleaved between the replays (the pattern under which a library reduction's memset node replayed out of order and
+    returned a stale bias gradient in round 2: no library reduction is left in the step) -- and two captured runs agree bit for bit."""
+    from msmp_pde_amd import train as T
+    from msmp_pde_amd.synthetic import make_case
+    bsz = 16
+    c = make_case('E2', bsz, seed=9, device='cuda', dtype=torch.float32)
+
+    def batches(k):
+        out = []
+        for i in range(k):
+            steps = [40 + 7 * i + (j % 5) for j in range(bsz)]
+            data, labels = c.creator.create_data(c.u_super, steps)
+            out.append(c.creator.create_graph(data, labels, c.x, c.variables, steps))
+        return out
+    gs = batches(7)
+
+    def run(captured):
+        torch.manual_seed(11)
+        model = mp.MODEL_NAMES[name](c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=3).cuda()
+        opt = mp.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[6], gamma=0.5)
+        losses, preds = [], []
+        if captured:
+            step = T.CapturedTrainStep(model, opt, gs[0], warmup=3)       # three eager iterations on gs[0], then the capture
+        else:
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                T.dp_loss_backward(model, gs[0])
+                opt.step()
+        for i, g in enumerate(gs):
+            if captured:
+                losses.append(step(g))
+            else:
+                opt.zero_grad(set_to_none=True)
+                losses.append(T.dp_loss_backward(model, g).detach().clone())
+                opt.step()
+            sched.step()
+            with torch.no_grad():                      # eager work between the replays, reading the freshly updated weights
+                preds.append(model(gs[(i + 1) % len(gs)]).clone())
+        torch.cuda.synchronize()
+        return losses, preds, [p.detach().clone() for p in model.parameters()]
+
+    le, pe, we = run(False)
+    lc, pc, wc = run(True)
+    lc2, pc2, wc2 = run(True)
+    print(name, 'losses', [round(float(l), 5) for l in lc])
+    assert all(torch.isfinite(l) for l in lc) and float(lc[-1]) != float(lc[0])
+    for i in range(len(le)):
+        assert torch.equal(le[i], lc[i]), (i, float(le[i]), float(lc[i]))
+        assert torch.equal(pe[i], pc[i]), i
+    for a, b, b2 in zip(we, wc, wc2):
+        assert torch.equal(a, b) and torch.equal(b, b2)
+    assert all(torch.equal(a, b) for a, b in zip(lc, lc2))
