@@ -17,6 +17,8 @@ HIP forward / backward pairs (autograd.py, lem.py) and the small encoder / decod
 `pde.tmax`, `pde.dt` are read at call time (they are mutated after construction, experiments/train.py:355-358).  Compute
 dtype is float32; the result is returned in the dtype of `data.x`.
 """
+import functools
+
 import torch
 from torch import nn
 
@@ -674,4 +676,7 @@ MODEL_NAMES = {   # experiments/train.py:34-183 getModel names -> class
     'LSTM': MP_PDE_SolverLSTMLin, 'LSTMGated': MP_PDE_SolverLSTMLinGated, 'LSTM2D': MP_PDE_Solver2DLSTMLin,
     'LSTMGated2D': MP_PDE_Solver2DLSTMLinGated,
     'MSGMP-PDE': MP_PDE_SolverLEMLinGatedGLU, 'MSGMP-PDE2D': MP_PDE_Solver2DLEMLinGatedGLU,
+    'SaveMSMP-PDE2D': functools.partial(MP_PDE_Solver2DLEMLinGated, save_state=True),       # train.py:126-131
 }
+# Not here: 'GLEMGated2D' (G_PDE_Solver2DLEMLinGated, models_gnn2D.py:1058: layers are torch_geometric's RGATConv, a third-party
+# attention layer outside this path's message / update functions) and the grid models BaseCNN / FNO / VNO (no message passing).

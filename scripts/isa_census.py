@@ -3,7 +3,7 @@
 import collections, sys
 lines = open(sys.argv[1]).read().splitlines()
 if len(sys.argv) > 2:
-    a = next(i for i, l in enumerate(lines) if l.startswith('_Z') and sys.argv[2] in l and l.rstrip().endswith(':'))
+    a = next(i for i, l in enumerate(lines) if l.startswith('_Z') and sys.argv[2] in l and (l.split(';')[0].rstrip().endswith(':')))
     b = next(i for i in range(a, len(lines)) if 's_endpgm' in lines[i])
     lines = lines[a:b + 1]
 seg, cnt = 0, collections.defaultdict(collections.Counter)

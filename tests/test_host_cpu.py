@@ -143,6 +143,21 @@ def test_glu_classes_have_the_reference_layout(mp, kind, comps):
     assert repr(model) == 'GNN' and mp.MODEL_NAMES['MSGMP-PDE' if comps == 1 else 'MSGMP-PDE2D'] is type(model)
 
 
+def test_model_names_cover_the_references_getmodel(mp):
+    """experiments/train.py:34-183: every name that constructs a message-passing GNN there constructs the mirror class here with the
+    same keyword arguments ('GLEMGated2D' = RGATConv layers and the grid models BaseCNN / FNO / VNO are other model families)."""
+    names_1d = ['MP-PDE', 'Gated', 'LEM', 'MSMP-PDE', 'MSSMP-PDE', 'MSGMP-PDE', 'SaveMSMP-PDE', 'LSTMGated', 'LSTM']
+    names_2d = ['MP-PDE2D', 'Gated2D', 'MSMP-PDE2D', 'MSGMP-PDE2D', 'SaveMSMP-PDE2D', 'MSG2-PDE2D', 'LSTMGated2D', 'LEM2D', 'LSTM2D']
+    assert set(mp.MODEL_NAMES) == set(names_1d + names_2d)
+    for name in names_1d + names_2d:
+        two_d = name.endswith('2D')
+        model = mp.MODEL_NAMES[name](pde=mp.AD() if two_d else mp.CE(), time_window=25, eq_variables={'a': 1.0, 'b': 1.0} if two_d else {'beta': 0.2},
+                                     hidden_layer=1)
+        assert repr(model) == 'GNN', name
+        if name.startswith('Save'):
+            assert isinstance(model.embedding_lem, mp.LEMS) and hasattr(model.embedding_lem, 'reset_states')
+
+
 def test_parameter_counts_match_survey(mp):
     """SURVEY.md section 8 config table (measured on the reference)."""
     n = lambda m: sum(p.numel() for p in m.parameters())
