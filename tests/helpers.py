@@ -84,7 +84,7 @@ TOL = 1e-5      # BASELINE.json north_star: "fp32 node output within 1e-5 of the
 
 
 FLOOR_FACTOR = 2.0       # on the max error and on the rms error.  Measured worst case of round 3 among the cases that miss the plain 1e-5
-FLOOR_FACTOR_RMS = 2.0   # (profiles/parity_r03.json): 1.49 x max / 1.43 x rms (an LSTM ablation); the six SURVEY section-8 classes <= 1.18 x / 0.87 x
+FLOOR_FACTOR_RMS = 2.0   # (profiles/parity_r03.json): 1.77 x max / 1.44 x rms (an LSTM ablation on WE3); the six SURVEY section-8 classes <= 1.36 x / 0.94 x
 
 
 def fp32_floors(kind, sd, g, pde, tw, eqv, layers):
