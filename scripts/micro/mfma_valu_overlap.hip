@@ -47,6 +47,19 @@ __global__ __launch_bounds__(512) void k(const float* in, float* out, int role_l
 #define NSTEP3 NSTEP(0) NSTEP(1) NSTEP(2)
             R16(NSTEP3)
         }
+    } else if (role == 20) {          // one MFMA + three v_exp_f32 alternating (transcendentals behind the wave's own MFMAs)
+        for (int it = 0; it < it_m; ++it) {
+#define TSTEP(J) { acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[J], 0, 0, 0); asm volatile("" : "+v"(acc[J])); ESTEP ESTEP ESTEP }
+#define TSTEP3 TSTEP(0) TSTEP(1) TSTEP(2)
+            R16(TSTEP3)
+        }
+    } else if (role == 21) {          // one MFMA + a dependent chain mul -> exp -> fma -> rcp -> mul (a Swish pair's shape)
+        for (int it = 0; it < it_m; ++it) {
+#define CSTEP(J) { acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[J], 0, 0, 0); asm volatile("" : "+v"(acc[J])); \
+                   asm volatile("v_mul_f32 %0, %0, %1\n\tv_exp_f32 %0, %0\n\tv_fma_f32 %0, %0, %1, %1\n\tv_rcp_f32 %0, %0\n\tv_mul_f32 %0, %0, %1" : "+v"(x[J]) : "v"(c)); }
+#define CSTEP3 CSTEP(0) CSTEP(1) CSTEP(2)
+            R16(CSTEP3)
+        }
     } else if (role == 4) {
         for (int it = 0; it < it_m; ++it) {
 #define XSTEP(J) { acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[J], 0, 0, 0); asm volatile("" : "+v"(acc[J])); VSTEP VSTEP VSTEP VSTEP VSTEP VSTEP }
@@ -88,6 +101,10 @@ int main() {
 #define NROW(N) printf("MFMA wave with s_nop of %2d cycles after each MFMA: alone %8.1f us, with a v_mul_f32 wave (76800) on the SIMD %8.1f us, with a v_exp_f32 wave (25600) %8.1f us\n", \
                4 * N, run<N>(in, out, 5, 0, it_m, 300), run<N>(in, out, 5, 2, it_m, 300), run<N>(in, out, 5, 3, it_m, 100));
     NROW(0) NROW(1) NROW(2) NROW(3) NROW(4) NROW(5) NROW(6) NROW(7)
+    printf("one wave per SIMD, 1 MFMA + 3 v_exp_f32 alternating (%d MFMAs, %d v_exp):           %8.1f us   (two waves per SIMD: %8.1f us)\n", it_m * 48, it_m * 48 * 3,
+           run(in, out, 20, 0, it_m, 0), run(in, out, 20, 20, it_m, 0));
+    printf("one wave per SIMD, 1 MFMA + a dependent mul-exp-fma-rcp-mul chain alternating:       %8.1f us   (two waves per SIMD: %8.1f us)\n",
+           run(in, out, 21, 0, it_m, 0), run(in, out, 21, 21, it_m, 0));
     printf("one wave per SIMD, 1 MFMA + 6 v_mul_f32 alternating (%d MFMAs, %d v_mul): %8.1f us\n", it_m * 48, it_m * 48 * 6, run(in, out, 4, 0, it_m, 0));
     printf("two waves per SIMD, the same each:                                        %8.1f us\n", run(in, out, 4, 4, it_m, 0));
     return 0;
