@@ -84,6 +84,8 @@ int msmp_last_status(int* flags_out, int reset);
  *   "bwd_gemm" 1 (default) / 2: msmp_mp_layer_bwd_f32 runs its row GEMMs on its own bf16x3 MFMA kernels (fused bias / Swish / dSwish epilogues;
  *             128-row workgroups from 32 768 rows on, 32-row workgroups whose waves split the output channels below);
  *             0: rocblas_sgemm + separate epilogue passes (A/B runs only: librocblas is loaded on first use).
+ *   "lem_tail" 1 (default): the LEM launch ends with a round of one-tile workgroups where that saves >= 0.3 of a round; 0: three-tile
+ *             workgroups only (same bits either way).
  *   "tile_arith" 1 (default): ranged tiles take their node rows by arithmetic on tile_halo; 0: always through the node list.
  *   "tail"    1 (default): msmp_mp_layer_f32 uses msmp_node_tail_f32 for graphs of up to 128 nodes; 0: the piecewise kernels.
  *   "pair"    gated pair: both heads' projection / message kernels in one launch each (bit-identical results): 0 never,

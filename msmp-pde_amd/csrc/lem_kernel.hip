@@ -316,6 +316,7 @@ struct LemWsArgs {
     const float* mlpb_s;    // [256]
     const float* scales;    // [8]
     float* out;
+    int full_wgs = 0x7fffffff;   // ws3: workgroups [0, full_wgs) take three 32-node tiles each, the ones behind them one tile each
 };
 
 constexpr int LEM_WS_FR = 1024;      // half8 per (tile) fragment area: [kt 4][s 2][plane 2][lane 64]
@@ -777,7 +778,14 @@ __global__ __launch_bounds__(512) void lem_encoder_ws3_kernel(LemWsArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: the role branches become scalar branches
     const int ks = wave & 3, role = wave >> 2;
     const int c = lane & 31, hh = lane >> 5;
-    const long n0 = (long)blockIdx.x * 96;
+    // A launch is cut into rounds of three-tile workgroups (one per CU) and, when that leaves at most a round of single tiles, a
+    // last round of ONE-tile workgroups: the recurrence of a tile is the dependent chain M_A -> V_A -> M_B -> V_B per step, three
+    // tiles fill it to 6 half-slots per step; a lone tile runs 4 (and with each wave alone on its SIMD): ~0.5 of the time, instead
+    // of a last round of three-tile workgroups that keeps a third of the CUs busy for a whole round (msmp_lem_encoder*: lem_partition).
+    const bool single = (int)blockIdx.x >= a.full_wgs;
+    const long n0 = single ? 96L * a.full_wgs + 32L * ((int)blockIdx.x - a.full_wgs) : (long)blockIdx.x * 96;
+    const long n_lim = single ? (n0 + 32 < a.n_nodes ? n0 + 32 : a.n_nodes) : a.n_nodes;      // nodes this workgroup writes
+    const int nt = single ? 1 : 3;
     const float LOG2E = 1.44269504088896340736f;
     const float inv_w = a.scales[4], inv_z = a.scales[5];
     const int T = a.t_len;
@@ -880,6 +888,25 @@ __global__ __launch_bounds__(512) void lem_encoder_ws3_kernel(LemWsArgs a) {
     using I2 = std::integral_constant<int, 2>;
 
     LPROF_DECL
+    if (single) {
+        // one tile: four half-slots per step, A's matrix / vector halves, then B's (4 T barriers for either role)
+        if (!role) {
+            fetch_x(I0{}, 0);
+            for (int t = 0; t < T; ++t) {
+                { half_m(I0{}); LPROF(lp_m); }                                                   LEM_SYNC();      // M_A
+                fetch_x(I0{}, t + 1 < T ? t + 1 : t); { half_v(I0{}); LPROF(lp_v); }             LEM_SYNC();      // V_A: z(t)
+                LEM_SYNC();
+                LEM_SYNC();
+            }
+        } else {
+            for (int t = 0; t < T; ++t) {
+                LEM_SYNC();
+                fetch_x(I0{}, t);                                                               LEM_SYNC();
+                { half_m(I0{}); LPROF(lp_m); }                                                   LEM_SYNC();      // M_B (reads z(t))
+                { half_v(I0{}); LPROF(lp_v); }                                                   LEM_SYNC();      // V_B: y(t)
+            }
+        }
+    } else
     // Two separate instruction streams (the role is wave-uniform): each executes 6 T + 3 barriers.
     if (!role) {
         fetch_x(I0{}, 0);
@@ -932,7 +959,7 @@ __global__ __launch_bounds__(512) void lem_encoder_ws3_kernel(LemWsArgs a) {
         // lemoutput_mlp: pass 0: role A takes tile 0, role B tile 1; pass 1: role A takes tile 2
         for (int pass = 0; pass < 2; ++pass) {
             const int X = pass ? 2 : role;
-            const bool work = pass == 0 || role == 0;
+            const bool work = (pass == 0 || role == 0) && X < nt;
             const half8* yb = yfr + X * LEM_WS_FR;
             half8* hb = zfr + X * LEM_WS_FR;
             if (work) {
@@ -967,7 +994,7 @@ __global__ __launch_bounds__(512) void lem_encoder_ws3_kernel(LemWsArgs a) {
                         res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][0], h0, res, 0, 0, 0);
                     }
                 const long n = n0 + 32 * X + c;
-                if (n < a.n_nodes) {
+                if (n < n_lim) {
                     float* o = a.out + (size_t)n * H + 32 * ks + 4 * hh;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -984,7 +1011,7 @@ __global__ __launch_bounds__(512) void lem_encoder_ws3_kernel(LemWsArgs a) {
 #pragma unroll
         for (int X = 0; X < 3; ++X) {
             const long n = n0 + 32 * X + c;
-            if (n < a.n_nodes) {
+            if (n < n_lim) {
                 float* o = a.out + (size_t)n * H + 32 * ks + 4 * hh;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1024,6 +1051,24 @@ extern "C" __attribute__((visibility("default"))) int msmp_debug_prof_lem(unsign
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof_lem), 16 * sizeof(unsigned long long));
 }
 #endif
+int g_lem_tail = 1;      // msmp_tune("lem_tail", 0): every workgroup of the ws3 kernel takes three tiles (no round of one-tile workgroups)
+// Partition of n_nodes into three-tile workgroups [0, full) and one-tile workgroups behind them (lem_encoder_ws3_kernel).  Cost
+// model in rounds of one workgroup per CU: a three-tile workgroup 1, a one-tile workgroup 0.5 (measured at 2048 graphs: 203 vs 99 us per
+// round at T = 25); the one-tile round is taken only when it saves at least 0.3 of a round (small launches measured slower with it).
+static unsigned lem_partition(int64_t n_nodes, int* full_wgs) {
+    const int64_t tiles = (n_nodes + 31) / 32, groups = (n_nodes + 95) / 96;
+    *full_wgs = 0x7fffffff;
+    if (!g_lem_tail) return (unsigned)groups;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const int64_t full = (groups / cus) * cus;               // whole rounds of three-tile workgroups
+    const int64_t rem = tiles - 3 * full;                    // tiles left for the last round(s)
+    if (rem <= 0) return (unsigned)groups;
+    const double all_three = (double)((groups + cus - 1) / cus), mixed = (double)(full / cus) + 0.5 * (double)((rem + cus - 1) / cus);
+    if (mixed > all_three - 0.3) return (unsigned)groups;
+    *full_wgs = (int)full;
+    return (unsigned)(full + rem);
+}
 int g_lem_nodes = 1;     // msmp_tune("lem_nodes", 0): msmp_lem_encoder_nodes_f32 declines, callers assemble the [N,T,ninp] tensor (A/B)
 int g_lem_split = 4;     // 4: weight-stationary anti-phased kernel (three node tiles), 3: weight-stationary two-tile kernel (round 2),
                          // 0: fp32 MFMA (msmp_tune "lem"; "split" 1/0 selects 4/0)
@@ -1060,7 +1105,7 @@ extern "C" int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len
     if (g_lem_split == 4) {
         LemWsArgs wa{xin, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s,
                      packed + L.mlp_s, packed + L.bias_s, packed + L.wx_h, packed + L.mlpb_s, packed + L.scales, h_out};
-        const unsigned g96 = (unsigned)((n_nodes + 95) / 96);
+        const unsigned g96 = lem_partition(n_nodes, &wa.full_wgs);
         hipStream_t st = (hipStream_t)stream;
         switch (ninp) {
             case 1: hipLaunchKernelGGL((lem_encoder_ws3_kernel<1, 0>), dim3(g96), dim3(512), 0, st, wa); break;
@@ -1114,7 +1159,7 @@ extern "C" int msmp_lem_encoder_nodes_f32(const float* u, const float* pos_x, co
     const LemLayout L = lem_layout();
     LemWsArgs wa{nullptr, u, pos_x, pos_t, vars, dt_cum, tw, nv, (long)n_nodes, tw, with_mlp, dt, packed + L.rec_s, packed + L.mlp_s,
                  packed + L.bias_s, packed + L.wx_h, packed + L.mlpb_s, packed + L.scales, h_out};
-    const unsigned g64 = (unsigned)((n_nodes + 63) / 64), g96 = (unsigned)((n_nodes + 95) / 96);
+    const unsigned g64 = (unsigned)((n_nodes + 63) / 64), g96 = g_lem_split == 4 ? lem_partition(n_nodes, &wa.full_wgs) : 0u;
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_LEM, st);
     if (g_lem_split == 4) {

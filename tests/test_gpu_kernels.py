@@ -418,6 +418,36 @@ def test_lem_encoder_kernel(mp, ninp, t_len, n):
         assert np.abs(hv.double().cpu().numpy() - ref_h).max() < 5e-6, variant
 
 
+@pytest.mark.parametrize('n', [33, 96 * 256 + 32 * 5 + 7, 96 * 256, 96 * 256 + 1, 204800, 96 * 512 + 32 * 256 + 1])
+def test_lem_one_tile_workgroups_are_bit_identical(mp, n):
+    """The LEM launch is cut into whole rounds of three-tile workgroups and, where that pays, a last round of ONE-tile workgroups
+    (msmp_tune("lem_tail"), lem_partition): a tile's arithmetic does not depend on which kind of workgroup ran it, so both
+    partitions give the same bits -- node counts around the round boundaries, a ragged last tile, the bench size, small batches
+    (one-tile workgroups only); with and without lemoutput_mlp, assembled and in-kernel step inputs."""
+    L = mp.lib()
+    torch.manual_seed(4)
+    ninp, t_len, nv = 4, 25, 2
+    lem = mp.LEM(ninp, 128).cuda()
+    mlp = torch.nn.Sequential(torch.nn.Linear(128, 128), mp.Swish(), torch.nn.Linear(128, 128), mp.Swish()).cuda()
+    xin = torch.randn(n, t_len, ninp, device='cuda') if n <= 30000 else None
+    u, pos_x, var = torch.randn(n, t_len, device='cuda'), torch.rand(n, 1, device='cuda'), torch.rand(n, nv, device='cuda')
+    dt = torch.cumsum(torch.ones(t_len, device='cuda') * 0.016, 0)
+    outs = {}
+    try:
+        for tail in (0, 1):
+            L.msmp_tune(b'lem_tail', tail)
+            with torch.no_grad():
+                o = [lem.encode_nodes(u, pos_x, pos_x, var, dt, False, mlp), lem.encode_nodes(u, pos_x, pos_x, var, dt, False, None)]
+                if xin is not None:
+                    o += [lem.encode(xin, mlp), lem.encode(xin, None)]
+            torch.cuda.synchronize()
+            outs[tail] = o
+    finally:
+        L.msmp_tune(b'lem_tail', 1)
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert a_ is not None and torch.isfinite(a_).all() and torch.equal(a_, b_)
+
+
 def test_fused_aggregate_degree_limits(mp):
     """Hub nodes: in-degree up to 256 runs fused; above that the fused entry point refuses (and
     msmp_mp_layer_f32 takes the message-tensor path), both matching the oracle."""
