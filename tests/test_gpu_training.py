@@ -590,8 +590,8 @@ def test_capturable_adamw_matches_the_host_step_count_form(mp):
     assert all(float(sd['state'][i]['step']) == 6.0 for i in range(3)) and '_msmp_dev' not in sd['param_groups'][0]
 
 
-@pytest.mark.parametrize('name', ['MSMP-PDE', 'MP-PDE'])
-def test_captured_training_step_follows_the_eager_trajectory(mp, name):
+@pytest.mark.parametrize('name,exp', [('MSMP-PDE', 'E2'), ('MP-PDE', 'E2'), ('Gated', 'WE3'), ('MSMP-PDE2D', 'RPU')])
+def test_captured_training_step_follows_the_eager_trajectory(mp, name, exp):
     """train.CapturedTrainStep (forward + loss + backward + AdamW of the reference's batch of 16 as ONE hipGraph launch) against the
     same iterations run eagerly: bit-identical losses and parameters over changing batches, with eager inference forwards of the
     model interleaved between the replays (the pattern under which a library reduction's memset node replayed out of order and
@@ -599,7 +599,7 @@ def test_captured_training_step_follows_the_eager_trajectory(mp, name):
     from msmp_pde_amd import train as T
     from msmp_pde_amd.synthetic import make_case
     bsz = 16
-    c = make_case('E2', bsz, seed=9, device='cuda', dtype=torch.float32)
+    c = make_case(exp, bsz, seed=9, device='cuda', dtype=torch.float32)
 
     def batches(k):
         out = []
