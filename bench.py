@@ -221,6 +221,7 @@ class SplitWorkload:
         for p in self.parts[1:]:
             p.model = self.parts[0].model
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.parts]
+        mp.lib().msmp_tune(b'lem_share', len(self.parts))       # the LEM launches of the sub-batches share the CUs: each plans its rounds for its share
         for s in self.streams:
             s.wait_stream(torch.cuda.current_stream(dev))
         self.model, self.graph, self.bsz = self.parts[0].model, self.parts[0].graph, n_graphs

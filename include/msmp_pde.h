@@ -84,6 +84,7 @@ int msmp_last_status(int* flags_out, int reset);
  *   "bwd_gemm" 1 (default) / 2: msmp_mp_layer_bwd_f32 runs its row GEMMs on its own bf16x3 MFMA kernels (fused bias / Swish / dSwish epilogues;
  *             128-row workgroups from 32 768 rows on, 32-row workgroups whose waves split the output channels below);
  *             0: rocblas_sgemm + separate epilogue passes (A/B runs only: librocblas is loaded on first use).
+ *   "lem_share" k (default 1): k LEM launches share the GPU (sub-batches on k streams): each plans its rounds for CUs / k.
  *   "lem_tail" 1 (default): the LEM launch ends with a round of one-tile workgroups where that saves >= 0.3 of a round; 0: three-tile
  *             workgroups only (same bits either way).
  *   "tile_arith" 1 (default): ranged tiles take their node rows by arithmetic on tile_halo; 0: always through the node list.

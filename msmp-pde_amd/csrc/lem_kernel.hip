@@ -1051,6 +1051,7 @@ extern "C" __attribute__((visibility("default"))) int msmp_debug_prof_lem(unsign
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof_lem), 16 * sizeof(unsigned long long));
 }
 #endif
+int g_lem_share = 1;     // msmp_tune("lem_share", k): k launches of this kind share the GPU (sub-batches on k streams): a launch plans for CUs / k
 int g_lem_tail = 1;      // msmp_tune("lem_tail", 0): every workgroup of the ws3 kernel takes three tiles (no round of one-tile workgroups)
 // Partition of n_nodes into three-tile workgroups [0, full) and one-tile workgroups behind them (lem_encoder_ws3_kernel).  Cost
 // model in rounds of one workgroup per CU: a three-tile workgroup 1, a one-tile workgroup 0.5 (measured at 2048 graphs: 203 vs 99 us per
@@ -1061,6 +1062,8 @@ static unsigned lem_partition(int64_t n_nodes, int* full_wgs) {
     if (!g_lem_tail) return (unsigned)groups;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cus = cus / (g_lem_share > 0 ? g_lem_share : 1);
+    if (cus < 1) cus = 1;
     const int64_t full = (groups / cus) * cus;               // whole rounds of three-tile workgroups
     const int64_t rem = tiles - 3 * full;                    // tiles left for the last round(s)
     if (rem <= 0) return (unsigned)groups;

@@ -1301,6 +1301,7 @@ using namespace msmp;
 extern int g_lem_split;
 extern int g_lem_nodes;
 extern int g_lem_tail;
+extern int g_lem_share;
 static int g_split = 1;      // fp16-split matrix path (default); msmp_tune("split", 0) selects the fp32-MFMA kernels
 
 extern "C" int msmp_edge_mlp_f32(const float* h, const float* u, const float* pos, const float* vars,
@@ -1356,6 +1357,7 @@ int msmp_tune_get(const char* key) {
     if (!strcmp(key, "tile")) return g_tile;
     if (!strcmp(key, "tile_arith")) return g_tile_arith;
     if (!strcmp(key, "lem_tail")) return g_lem_tail;
+    if (!strcmp(key, "lem_share")) return g_lem_share;
     return 0;
 }
 
@@ -1368,6 +1370,7 @@ extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "tile")) { g_tile = value; return MSMP_OK; }
     if (key && !strcmp(key, "tile_arith")) { g_tile_arith = value; return MSMP_OK; }
     if (key && !strcmp(key, "lem_tail")) { g_lem_tail = value != 0; return MSMP_OK; }
+    if (key && !strcmp(key, "lem_share") && value >= 1 && value <= 16) { g_lem_share = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
     if (key && !strcmp(key, "lem")) { g_lem_split = value; return MSMP_OK; }
     if (key && !strcmp(key, "lem_nodes")) { g_lem_nodes = value; return MSMP_OK; }

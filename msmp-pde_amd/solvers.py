@@ -373,18 +373,23 @@ class _SolverBase(nn.Module):
 
     def _forward_sub_batches(self, data, parts):
         plan = self._sub_batch_plan(data, parts)
+        share = lib().msmp_tune_query(b'lem_share')
+        lib().msmp_tune(b'lem_share', max(1, len(plan['subs'])))        # the sub-batches' LEM launches share the CUs (restored below)
         n = data.x.shape[0]
         cur = torch.cuda.current_stream()
         out = None
         per_node = [k for k, v in data.__dict__.items() if torch.is_tensor(v) and not k.startswith('_') and k not in ('edge_index', 'batch')
                     and v.dim() >= 1 and v.shape[0] == n]
         outs = []
-        for sub, (n0, n1), st in zip(plan['subs'], plan['offs'], plan['streams']):
-            for k in per_node:                                  # this step's node rows: views of the caller's tensors
-                setattr(sub, k, getattr(data, k)[n0:n1])
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                outs.append(self._forward(sub))
+        try:
+            for sub, (n0, n1), st in zip(plan['subs'], plan['offs'], plan['streams']):
+                for k in per_node:                              # this step's node rows: views of the caller's tensors
+                    setattr(sub, k, getattr(data, k)[n0:n1])
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    outs.append(self._forward(sub))
+        finally:
+            lib().msmp_tune(b'lem_share', share)
         for o, st in zip(outs, plan['streams']):
             cur.wait_stream(st)
             o.record_stream(cur)                                # allocated on the side stream, consumed on the caller's
