@@ -12,6 +12,10 @@ from . import _lib
 from ._lib import lib, check, ptr, current_stream
 
 
+import os as _os
+_NO_SLICE = _os.environ.get('MSMP_NO_WINDOW_SLICE') == '1'       # A/B switch of create_data's zero-copy window (scripts only)
+
+
 class Data(object):
     """Attribute bag standing in for torch_geometric.data.Data (common/utils.py:382-385):
     x [N,Tw], y, pos [N,2] (t, x), batch [N] int64, edge_index [2,E] int64, plus the per-experiment
@@ -251,6 +255,12 @@ class GraphCreator(object):
     # -- common/utils.py:300-317
     def create_data(self, datapoints, steps):
         dev, tw = datapoints.device, self.tw
+        if not torch.is_tensor(steps) and len(steps) > 0 and all(int(s) == int(steps[0]) for s in steps) and not _NO_SLICE:
+            # every sample at the same step (the rollout loops of the reference, train_helper.py:255-273 `same_steps`): the window is a
+            # plain slice of the trajectory tensor -- views, no gather kernel (a 41-MB indexed copy per rollout step at 2048 graphs)
+            s0 = int(steps[0])
+            if tw <= s0 <= datapoints.shape[1] - tw:
+                return datapoints[:, s0 - tw:s0], datapoints[:, s0:s0 + tw]
         steps_t = self._steps_on(steps, dev)
         b = self._cached(('b', datapoints.shape[0], str(dev)), lambda: torch.arange(datapoints.shape[0], device=dev)[:, None])
         win = self._cached(('win', tw, str(dev)), lambda: torch.arange(-tw, tw, device=dev)[None, :])
