@@ -187,29 +187,39 @@ __device__ __forceinline__ float prep_div(const void* p, int f64, long i, double
     return f64 ? (float)(reinterpret_cast<const double*>(p)[i] / d) : reinterpret_cast<const float*>(p)[i] / (float)d;
 }
 __global__ __launch_bounds__(256) void prepare_nodes_kernel(PrepArgs a) {
+    // thread = (node, four consecutive columns of the packed row): one 16-byte store of the feature row per thread
+    const int groups = a.stride >> 2;                                  // 8, 16 or 24
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n * a.stride) return;
-    const long node = i / a.stride;
-    const int k = (int)(i - node * a.stride);
+    if (i >= a.n * groups) return;
+    const long node = groups == 8 ? i >> 3 : (groups == 16 ? i >> 4 : i / groups);
+    const int k0 = 4 * (int)(i - node * groups);
     const int nv = 1 + a.n_cols;
-    float v = 0.f;
-    if (k < a.tw) {
-        v = prep_load(a.x, a.x_f64, node * a.tw + k);
-        a.u[node * a.tw + k] = v;
-    } else if (k == a.tw) {
-        v = prep_div(a.pos, a.pos_f64, 2 * node + 1, a.L);
-        a.pos_x[node] = v;
-    } else if (k == a.tw + 1) {
-        v = prep_div(a.pos, a.pos_f64, 2 * node, a.tmax);
-        a.pos_t[node] = v;
-        a.vars[node * nv] = v;
-    } else if (k <= a.tw + nv) {
-        const int c = k - a.tw - 2;
-        v = prep_div(a.col[c], a.col_f64[c], node, a.col_div[c]);
-        a.vars[node * nv + 1 + c] = v;
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    bool bad = false;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int k = k0 + m;
+        float v = 0.f;
+        if (k < a.tw) {
+            v = prep_load(a.x, a.x_f64, node * a.tw + k);
+            a.u[node * a.tw + k] = v;
+        } else if (k == a.tw) {
+            v = prep_div(a.pos, a.pos_f64, 2 * node + 1, a.L);
+            a.pos_x[node] = v;
+        } else if (k == a.tw + 1) {
+            v = prep_div(a.pos, a.pos_f64, 2 * node, a.tmax);
+            a.pos_t[node] = v;
+            a.vars[node * nv] = v;
+        } else if (k <= a.tw + nv) {
+            const int c = k - a.tw - 2;
+            v = prep_div(a.col[c], a.col_f64[c], node, a.col_div[c]);
+            a.vars[node * nv + 1 + c] = v;
+        }
+        out[m] = v;
+        bad |= out_of_range(v);
     }
-    if (a.feat) a.feat[i] = v;
-    if (out_of_range(v)) status_raise(a.status, MSMP_STATUS_INPUT_RANGE);        // the split path saturates node rows at |x| = 255.87
+    if (a.feat) *reinterpret_cast<f32x4*>(a.feat + node * a.stride + k0) = out;
+    if (bad) status_raise(a.status, MSMP_STATUS_INPUT_RANGE);        // the split path saturates node rows at |x| = 255.87
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -750,7 +760,7 @@ extern "C" int msmp_prepare_nodes(const void* x, int x_f64, const void* pos, int
         MSMP_REQUIRE(cols[c] && col_div[c] != 0.0, MSMP_ERR_ARG, "msmp_prepare_nodes: bad column %d", c);
         a.col[c] = cols[c]; a.col_f64[c] = col_f64[c]; a.col_div[c] = col_div[c];
     }
-    const long total = (long)n_nodes * stride;
+    const long total = (long)n_nodes * (stride / 4);
     hipLaunchKernelGGL(prepare_nodes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("prepare_nodes_kernel");
 }
