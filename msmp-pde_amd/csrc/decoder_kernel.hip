@@ -79,6 +79,104 @@ __global__ __launch_bounds__(256) void decoder_kernel(DecArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// The same decoder with EIGHT lanes per node, split by position (default since round 3).  decoder_kernel above keeps a node's
+// whole row and both intermediate arrays in one lane's registers: 256 VGPRs + 250 AGPRs, ONE wave per SIMD, which issues at most one
+// vector instruction per 4.4 clocks (scripts/micro/valu_issue.hip) on a SIMD that takes two -- 112 us per launch at 2048 graphs for
+// 8.9 k instructions per wave, in 3.125 -> 4 rounds.  Here lane q of a node computes the intermediate positions
+// [q PP, (q + 1) PP) of all eight channels from a 26-28-value window of the row, the node's 8 x L1 intermediates meet in LDS,
+// and lane q then forms OPL consecutive outputs from a (OPL + K2 - 1)-value window per channel.  < 100 registers, three
+// workgroups per CU.  The taps of every sum are added in the order of decoder_kernel: the same bits.
+// ----------------------------------------------------------------------------------------------
+template <int TW, int K1, int S1, int K2>
+struct DecSplit {
+    static constexpr int L1 = (H - K1) / S1 + 1;
+    static constexpr int PP = (L1 + 7) / 8;                          // intermediate positions per lane
+    static constexpr int XW = (PP - 1) * S1 + K1;                    // row values a lane needs
+    static constexpr int OPL = TW > 32 ? 8 : 4;                      // consecutive outputs per lane (multiple of 4: aligned 16-byte LDS reads)
+    static constexpr int MW = OPL + K2 - 1;                          // intermediate values per channel a lane needs for them
+    static constexpr int MW4 = (MW + 3) / 4;
+    static constexpr int LP = ((7 * OPL + 4 * MW4 > L1 ? 7 * OPL + 4 * MW4 : L1) + 3) / 4 * 4 + 4;      // padded row of the LDS table
+    static constexpr int NODES = 8 * LP * 4 * 32 <= 49152 ? 32 : 16;  // nodes per workgroup (LDS <= 48 KB)
+    static_assert(L1 - K2 + 1 == TW && 8 * OPL >= TW, "decoder geometry");
+};
+
+template <int TW, int K1, int S1, int K2>
+__global__ __launch_bounds__(256) void decoder_split_kernel(DecArgs a) {
+    using G = DecSplit<TW, K1, S1, K2>;
+    constexpr int L1 = G::L1, PP = G::PP, XW = G::XW, OPL = G::OPL, MW4 = G::MW4, LP = G::LP, NODES = G::NODES;
+    __shared__ __attribute__((aligned(16))) float mid[NODES * 8 * LP];
+    const int q = threadIdx.x & 7, nl = threadIdx.x >> 3;
+    const long n = (long)blockIdx.x * NODES + nl;
+    const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
+    // ---- the lane's window of the row: positions p0 .. p0 + PP - 1 read x[p0 S1 .. p0 S1 + XW) (clamped inside the row) ----------
+    const int p0 = q * PP;
+    float x[XW];
+    {
+        const float* row = a.h + (size_t)nc * H;
+        const int x0 = p0 * S1;
+#pragma unroll
+        for (int i = 0; i < XW; ++i) x[i] = row[x0 + i < H ? x0 + i : H - 1];
+    }
+    float* mrow = mid + (size_t)nl * 8 * LP;
+#pragma unroll 1
+    for (int c = 0; c < 8; ++c) {
+        float w1c[K1];
+#pragma unroll
+        for (int j = 0; j < K1; ++j) w1c[j] = a.w1[c * K1 + j];
+        const float bc = a.b1[c];
+        float s[PP];
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) s[pp] = bc;
+#pragma unroll
+        for (int j = 0; j < K1; ++j)
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) s[pp] = fmaf(w1c[j], x[pp * S1 + j], s[pp]);
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp)
+            if (p0 + pp < L1) mrow[c * LP + p0 + pp] = swishf(s[pp]);
+    }
+    __syncthreads();
+    // ---- outputs t0 .. t0 + OPL - 1 of this lane -------------------------------------------------------------------------
+    const int t0 = q * OPL;
+    float o[OPL];
+    const float bias2 = a.b2[0];
+#pragma unroll
+    for (int i = 0; i < OPL; ++i) o[i] = bias2;
+#pragma unroll 1
+    for (int c = 0; c < 8; ++c) {
+        float w2c[K2];
+#pragma unroll
+        for (int j = 0; j < K2; ++j) w2c[j] = a.w2[c * K2 + j];
+        float m[4 * MW4];
+#pragma unroll
+        for (int i = 0; i < MW4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(mrow + c * LP + t0 + 4 * i);
+            m[4 * i] = v[0]; m[4 * i + 1] = v[1]; m[4 * i + 2] = v[2]; m[4 * i + 3] = v[3];
+        }
+#pragma unroll
+        for (int j = 0; j < K2; ++j)
+#pragma unroll
+            for (int i = 0; i < OPL; ++i) o[i] = fmaf(w2c[j], m[i + j], o[i]);
+    }
+    if (n >= a.n_nodes || t0 >= TW) return;
+    float* op = a.out + (size_t)n * TW;
+    if (a.u == nullptr) {
+#pragma unroll
+        for (int i = 0; i < OPL; ++i)
+            if (t0 + i < TW) op[t0 + i] = o[i];
+        return;
+    }
+    const float ul = a.u[(size_t)n * TW + TW - 1];
+    float tcum = 0.f;
+    for (int t = 0; t < t0; ++t) tcum += a.dt;          // cumsum of a constant, float32 partial sums like torch.cumsum on the device
+#pragma unroll
+    for (int i = 0; i < OPL; ++i) {
+        tcum += a.dt;
+        if (t0 + i < TW) op[t0 + i] = ul + tcum * o[i];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // Decoder of the *2D solver classes (two solution components), experiments/models_gnn2D.py:79-88, 125-141:
 //   diff = Conv1d(8 -> 2, k2)( Swish( Conv1d(2 -> 8, k1, stride s1)( hd ) ) ),   hd = double_mlp(h)  [N, 2, 128]
 //   out  = unflatten(u) + cumsum(dt) * diff, flattened back to [N, 2*tw]
@@ -200,7 +298,17 @@ extern "C" int msmp_decoder_f32(const float* h, const float* u, int64_t n_nodes,
     const unsigned grid = (unsigned)((n_nodes + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_DECODER, st);
-    switch (tw) {   // experiments/models_gnn.py:210-224
+#define MSMP_DEC_SPLIT(TW_, K1_, S1_, K2_) do { using G_ = DecSplit<TW_, K1_, S1_, K2_>; \
+        hipLaunchKernelGGL((decoder_split_kernel<TW_, K1_, S1_, K2_>), dim3((unsigned)((n_nodes + G_::NODES - 1) / G_::NODES)), dim3(G_::NODES * 8), 0, st, a); } while (0)
+    if (msmp_tune_get("decoder")) switch (tw) {   // experiments/models_gnn.py:210-224
+        case 20: MSMP_DEC_SPLIT(20, 15, 4, 10); break;
+        case 25: MSMP_DEC_SPLIT(25, 16, 3, 14); break;
+        case 50: MSMP_DEC_SPLIT(50, 12, 2, 10); break;
+        default:
+            set_error("msmp_decoder_f32: time_window %d (the reference defines 20, 25, 50)", tw);
+            return MSMP_ERR_UNSUPPORTED;
+    } else
+    switch (tw) {   // the one-lane-per-node edition (msmp_tune("decoder", 0))
         case 20: hipLaunchKernelGGL((decoder_kernel<20, 15, 4, 10>), dim3(grid), dim3(256), 0, st, a); break;
         case 25: hipLaunchKernelGGL((decoder_kernel<25, 16, 3, 14>), dim3(grid), dim3(256), 0, st, a); break;
         case 50: hipLaunchKernelGGL((decoder_kernel<50, 12, 2, 10>), dim3(grid), dim3(256), 0, st, a); break;
@@ -208,6 +316,7 @@ extern "C" int msmp_decoder_f32(const float* h, const float* u, int64_t n_nodes,
             set_error("msmp_decoder_f32: time_window %d (the reference defines 20, 25, 50)", tw);
             return MSMP_ERR_UNSUPPORTED;
     }
+#undef MSMP_DEC_SPLIT
     timing_end(MSMP_K_DECODER, st);
     return check_launch("decoder_kernel");
 }

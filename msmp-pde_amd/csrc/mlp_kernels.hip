@@ -1345,6 +1345,7 @@ static int g_edge_nb = 0;    // tuning override (msmp_tune): 0 = automatic, 1 / 
 
 static int g_pair = 1;       // gated pair: both heads' projection / message kernels in one launch each: 0 never, 1 up to PAIR_MAX_NODES nodes, 2 always
 constexpr int64_t PAIR_MAX_NODES = 65536;     // measured (E2, ms per rollout step, per-head vs paired): 256 graphs 1.33 / 1.14, 512: 2.06 / 1.95, 1024: 3.63 / 3.65, 2048: 6.95 / 7.07
+static int g_decoder = 1;     // 1-D decoder: 1 = eight lanes per node, split by position; 0 = one lane per node (decoder_kernel.hip)
 static int g_tile_arith = 1;  // ranged tiles: slot -> node arithmetically (tile_halo) instead of through the node list
 static int g_tile = 2;       // node tiles (tile_kernels.hip): 2 fold the projections into the message kernel, 1 staged P / Q rows, 0 off
 static int g_bwd_gemm = 1;   // layer backward: row GEMMs on rows_gemm_kernel (bf16x3 MFMA, fused epilogues); 0: rocblas_sgemm + separate passes
@@ -1356,6 +1357,7 @@ int msmp_tune_get(const char* key) {
     if (!strcmp(key, "pair")) return g_pair;
     if (!strcmp(key, "tile")) return g_tile;
     if (!strcmp(key, "tile_arith")) return g_tile_arith;
+    if (!strcmp(key, "decoder")) return g_decoder;
     if (!strcmp(key, "lem_tail")) return g_lem_tail;
     if (!strcmp(key, "lem_share")) return g_lem_share;
     return 0;
@@ -1369,6 +1371,7 @@ extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "pair")) { g_pair = value; return MSMP_OK; }
     if (key && !strcmp(key, "tile")) { g_tile = value; return MSMP_OK; }
     if (key && !strcmp(key, "tile_arith")) { g_tile_arith = value; return MSMP_OK; }
+    if (key && !strcmp(key, "decoder")) { g_decoder = value != 0; return MSMP_OK; }
     if (key && !strcmp(key, "lem_tail")) { g_lem_tail = value != 0; return MSMP_OK; }
     if (key && !strcmp(key, "lem_share") && value >= 1 && value <= 16) { g_lem_share = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }

@@ -503,6 +503,21 @@ def test_decoder_kernel(mp, tw):
     ref = f(u)[:, -1:] + np.cumsum(np.ones(tw) * dt)[None, :] * diff
     err = np.abs(out.double().cpu().numpy() - ref).max()
     assert err < 1e-6, err
+    # the one-lane-per-node edition (msmp_tune("decoder", 0)) adds every sum's taps in the same order: the same bits; and the
+    # output-only mode (MSSMP_PDE_Solver_sub) of both
+    L = mp.lib()
+    try:
+        L.msmp_tune(b'decoder', 0)
+        old = torch.empty(n, tw, device='cuda')
+        check(L.msmp_decoder_f32(ptr(t[0]), ptr(t[1]), n, tw, ptr(t[2]), ptr(t[3]), ptr(t[4]), ptr(t[5]), dt, ptr(old), current_stream()), 'decoder')
+        old_d = torch.empty(n, tw, device='cuda')
+        check(L.msmp_decoder_f32(ptr(t[0]), None, n, tw, ptr(t[2]), ptr(t[3]), ptr(t[4]), ptr(t[5]), dt, ptr(old_d), current_stream()), 'decoder')
+    finally:
+        L.msmp_tune(b'decoder', 1)
+    new_d = torch.empty(n, tw, device='cuda')
+    check(L.msmp_decoder_f32(ptr(t[0]), None, n, tw, ptr(t[2]), ptr(t[3]), ptr(t[4]), ptr(t[5]), dt, ptr(new_d), current_stream()), 'decoder')
+    assert torch.equal(out, old) and torch.equal(new_d, old_d)
+    assert np.abs(new_d.double().cpu().numpy() - diff).max() < 1e-6
 
 
 @pytest.mark.parametrize('tw', [25, 50])
