@@ -266,6 +266,96 @@ __global__ __launch_bounds__(256) void decoder2d_kernel(Dec2Args a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// The *2D decoder split by position like decoder_split_kernel (eight lanes per node; decoder2d_kernel keeps a 128-value input row,
+// 38-59 intermediates and 2 tw partial outputs per lane).  Lane q builds the intermediate positions [q PP, (q + 1) PP) of all eight
+// channels from windows of BOTH input rows, the node's 8 x L1 intermediates meet in LDS, lane q forms OPL consecutive outputs of both
+// components.  Sums are formed exactly as decoder2d_kernel forms them -- per channel over the taps, the eight channel sums in the
+// order of its xor-shuffle tree, then the bias -- the same bits.
+// ----------------------------------------------------------------------------------------------
+template <int TW, int K1, int S1, int K2>
+__global__ __launch_bounds__(256) void decoder2d_split_kernel(Dec2Args a) {
+    using G = DecSplit<TW, K1, S1, K2>;
+    constexpr int L1 = G::L1, PP = G::PP, XW = G::XW, OPL = G::OPL, MW4 = G::MW4, LP = G::LP, NODES = G::NODES;
+    __shared__ __attribute__((aligned(16))) float mid[NODES * 8 * LP];
+    const int q = threadIdx.x & 7, nl = threadIdx.x >> 3;
+    const long n = (long)blockIdx.x * NODES + nl;
+    const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
+    const int p0 = q * PP;
+    float x[2][XW];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const float* row = a.hd + ((size_t)nc * 2 + ci) * H;
+        const int x0 = p0 * S1;
+#pragma unroll
+        for (int i = 0; i < XW; ++i) x[ci][i] = row[x0 + i < H ? x0 + i : H - 1];
+    }
+    float* mrow = mid + (size_t)nl * 8 * LP;
+#pragma unroll 1
+    for (int c = 0; c < 8; ++c) {
+        const float bc = a.b1[c];
+        float s[PP];
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) s[pp] = bc;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+            float w[K1];
+#pragma unroll
+            for (int j = 0; j < K1; ++j) w[j] = a.w1[(c * 2 + ci) * K1 + j];
+#pragma unroll
+            for (int j = 0; j < K1; ++j)
+#pragma unroll
+                for (int pp = 0; pp < PP; ++pp) s[pp] = fmaf(w[j], x[ci][pp * S1 + j], s[pp]);
+        }
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp)
+            if (p0 + pp < L1) mrow[c * LP + p0 + pp] = swishf(s[pp]);
+    }
+    __syncthreads();
+    const int t0 = q * OPL;
+    float sc[2][8][OPL];          // per component and channel: the tap sums of this lane's outputs
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float m[4 * MW4];
+#pragma unroll
+        for (int i = 0; i < MW4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(mrow + c * LP + t0 + 4 * i);
+            m[4 * i] = v[0]; m[4 * i + 1] = v[1]; m[4 * i + 2] = v[2]; m[4 * i + 3] = v[3];
+        }
+#pragma unroll
+        for (int co = 0; co < 2; ++co) {
+            float w[K2];
+#pragma unroll
+            for (int j = 0; j < K2; ++j) w[j] = a.w2[(co * 8 + c) * K2 + j];
+#pragma unroll
+            for (int i = 0; i < OPL; ++i) sc[co][c][i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < K2; ++j)
+#pragma unroll
+                for (int i = 0; i < OPL; ++i) sc[co][c][i] = fmaf(w[j], m[i + j], sc[co][c][i]);
+        }
+    }
+    if (n >= a.n_nodes || t0 >= TW) return;
+    const float b2v[2] = {a.b2[0], a.b2[1]};
+    float tcum = 0.f;
+    for (int t = 0; t < t0; ++t) tcum += a.dt;
+#pragma unroll
+    for (int i = 0; i < OPL; ++i) {
+        tcum += a.dt;
+        if (t0 + i < TW) {
+#pragma unroll
+            for (int co = 0; co < 2; ++co) {
+                // the xor-shuffle tree of decoder2d_kernel: pairs, pairs of pairs, halves
+                const float s01 = sc[co][0][i] + sc[co][1][i], s23 = sc[co][2][i] + sc[co][3][i];
+                const float s45 = sc[co][4][i] + sc[co][5][i], s67 = sc[co][6][i] + sc[co][7][i];
+                const float v = (s01 + s23) + (s45 + s67);
+                const size_t o = (size_t)n * 2 * TW + co * TW + t0 + i;
+                a.out[o] = a.u[o] + tcum * (v + b2v[co]);
+            }
+        }
+    }
+}
+
 }  // namespace msmp
 
 using namespace msmp;
@@ -278,6 +368,12 @@ extern "C" int msmp_decoder2d_f32(const float* hd, const float* u, int64_t n_nod
     const unsigned grid = (unsigned)((n_nodes + 31) / 32);
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_DECODER, st);
+#define MSMP_DEC2_SPLIT(TW_, K1_, S1_, K2_) do { using G_ = DecSplit<TW_, K1_, S1_, K2_>; \
+        hipLaunchKernelGGL((decoder2d_split_kernel<TW_, K1_, S1_, K2_>), dim3((unsigned)((n_nodes + G_::NODES - 1) / G_::NODES)), dim3(G_::NODES * 8), 0, st, a); } while (0)
+    if (msmp_tune_get("decoder") && (tw == 25 || tw == 50)) {
+        if (tw == 25) MSMP_DEC2_SPLIT(25, 16, 3, 14); else MSMP_DEC2_SPLIT(50, 12, 2, 10);
+    } else
+#undef MSMP_DEC2_SPLIT_GUARD
     switch (tw) {   // experiments/models_gnn2D.py:79-88
         case 25: hipLaunchKernelGGL((decoder2d_kernel<25, 16, 3, 14>), dim3(grid), dim3(256), 0, st, a); break;
         case 50: hipLaunchKernelGGL((decoder2d_kernel<50, 12, 2, 10>), dim3(grid), dim3(256), 0, st, a); break;

@@ -541,6 +541,14 @@ def test_decoder2d_kernel(mp, tw):
     ref = (f(u).reshape(n, 2, tw) + np.cumsum(np.ones(tw) * dt)[None, None, :] * diff).reshape(n, 2 * tw)
     err = np.abs(out.double().cpu().numpy() - ref).max()
     assert err < 1e-6, err
+    L = mp.lib()                         # the channel-per-lane edition forms the same sums in the same order: the same bits
+    try:
+        L.msmp_tune(b'decoder', 0)
+        old = torch.empty(n, 2 * tw, device='cuda')
+        check(L.msmp_decoder2d_f32(ptr(t[0]), ptr(t[1]), n, tw, ptr(t[2]), ptr(t[3]), ptr(t[4]), ptr(t[5]), dt, ptr(old), current_stream()), 'decoder2d')
+    finally:
+        L.msmp_tune(b'decoder', 1)
+    assert torch.equal(out, old)
 
 
 @pytest.mark.parametrize('k_in,n', [(28, 777), (29, 128), (59, 1000), (105, 333), (128, 129), (1, 64)])
