@@ -1056,14 +1056,10 @@ int g_lem_tail = 1;      // msmp_tune("lem_tail", 0): every workgroup of the ws3
 // Partition of n_nodes into three-tile workgroups [0, full) and one-tile workgroups behind them (lem_encoder_ws3_kernel).  Cost
 // model in rounds of one workgroup per CU: a three-tile workgroup 1, a one-tile workgroup 0.5 (measured at 2048 graphs: 203 vs 99 us per
 // round at T = 25); the one-tile round is taken only when it saves at least 0.3 of a round (small launches measured slower with it).
-static unsigned lem_partition(int64_t n_nodes, int* full_wgs) {
+static unsigned lem_partition_for(int64_t n_nodes, int cus, int tail, int* full_wgs) {
     const int64_t tiles = (n_nodes + 31) / 32, groups = (n_nodes + 95) / 96;
     *full_wgs = 0x7fffffff;
-    if (!g_lem_tail) return (unsigned)groups;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    cus = cus / (g_lem_share > 0 ? g_lem_share : 1);
-    if (cus < 1) cus = 1;
+    if (!tail || cus < 1) return (unsigned)groups;
     const int64_t full = (groups / cus) * cus;               // whole rounds of three-tile workgroups
     const int64_t rem = tiles - 3 * full;                    // tiles left for the last round(s)
     if (rem <= 0) return (unsigned)groups;
@@ -1071,6 +1067,21 @@ static unsigned lem_partition(int64_t n_nodes, int* full_wgs) {
     if (mixed > all_three - 0.3) return (unsigned)groups;
     *full_wgs = (int)full;
     return (unsigned)(full + rem);
+}
+static unsigned lem_partition(int64_t n_nodes, int* full_wgs) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cus = cus / (g_lem_share > 0 ? g_lem_share : 1);
+    if (cus < 1) cus = 1;
+    return lem_partition_for(n_nodes, cus, g_lem_tail, full_wgs);
+}
+// (tests, no GPU needed) the partition of n_nodes for a device of `cus` CUs: grid size and the number of three-tile workgroups
+extern "C" __attribute__((visibility("default"))) int msmp_debug_lem_partition(int64_t n_nodes, int cus, int64_t* grid_out, int64_t* full_out) {
+    int full = 0;
+    const unsigned g = lem_partition_for(n_nodes, cus, 1, &full);
+    if (grid_out) *grid_out = g;
+    if (full_out) *full_out = full == 0x7fffffff ? (int64_t)g : full;
+    return 0;
 }
 int g_lem_nodes = 1;     // msmp_tune("lem_nodes", 0): msmp_lem_encoder_nodes_f32 declines, callers assemble the [N,T,ninp] tensor (A/B)
 int g_lem_split = 4;     // 4: weight-stationary anti-phased kernel (three node tiles), 3: weight-stationary two-tile kernel (round 2),

@@ -158,6 +158,34 @@ def test_model_names_cover_the_references_getmodel(mp):
             assert isinstance(model.embedding_lem, mp.LEMS) and hasattr(model.embedding_lem, 'reset_states')
 
 
+def test_lem_launch_partition_covers_every_node(mp):
+    """lem_partition (lem_kernel.hip): workgroups [0, full) take 96 nodes each from node 96 b, the ones behind them 32 nodes each
+    from 96 full + 32 (b - full): for every node count and device size the workgroups must tile [0, n) without gap or overlap, and the
+    one-tile round may only be chosen where it is modelled cheaper."""
+    import ctypes
+    L = ctypes.CDLL(mp.LIB_PATH)
+    L.msmp_debug_lem_partition.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    rng = np.random.default_rng(0)
+    cases = [(n, cus) for cus in (1, 7, 128, 256, 304) for n in list(range(1, 400)) + [96 * cus + d for d in (-33, -1, 0, 1, 31, 32, 33, 95, 96, 97)]
+             + [204800, 25600, 12800, 3200] + [int(x) for x in rng.integers(1, 3_000_000, 40)] if n > 0]
+    mixed = 0
+    for n, cus in cases:
+        g, f = ctypes.c_int64(), ctypes.c_int64()
+        assert L.msmp_debug_lem_partition(n, cus, ctypes.byref(g), ctypes.byref(f)) == 0
+        grid, full = g.value, f.value
+        assert 0 <= full <= grid and grid >= 1
+        covered = 96 * full + 32 * (grid - full)
+        assert covered >= n, (n, cus, grid, full)
+        if full == grid:                                  # three-tile workgroups only: the last one may be ragged
+            assert grid == (n + 95) // 96
+        else:                                             # whole rounds of three-tile workgroups, then one-tile workgroups up to n
+            assert full % cus == 0 and 96 * full < n and covered - n < 32 and (grid - full) >= 1
+            rounds3, rounds_mixed = -(-((n + 95) // 96) // cus), full // cus + 0.5 * -(-(grid - full) // cus)
+            assert rounds_mixed <= rounds3 - 0.3 + 1e-9
+            mixed += 1
+    assert mixed > 50
+
+
 def test_parameter_counts_match_survey(mp):
     """SURVEY.md section 8 config table (measured on the reference)."""
     n = lambda m: sum(p.numel() for p in m.parameters())
