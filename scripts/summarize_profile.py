@@ -12,6 +12,7 @@ import sys
 from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+KEEP_TRAFFIC_JSON = '--no-traffic-json' in sys.argv      # profiles of the non-default configs must not replace the default workload's stamp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, 'gpurun_out', tag)
 dst = os.path.join(ROOT, 'profiles')
@@ -43,7 +44,9 @@ def counter(path, name):
 fetch = counter(os.path.join(src, 'pmc_fetch.csv'), 'FETCH_SIZE')
 write = counter(os.path.join(src, 'pmc_write.csv'), 'WRITE_SIZE')
 traffic = {}
-lines = [f'# rocprofv3 summary `{tag}` (MI355X, bench.py default workload: E2 MSMP-PDE, 2048 graphs)', '']
+_stamp_file = os.path.join(src, 'stamp.json')
+_wl = json.load(open(_stamp_file)).get('workload', 'E2/MSMP-PDE/2048/n3') if os.path.exists(_stamp_file) else 'E2/MSMP-PDE/2048/n3'
+lines = [f'# rocprofv3 summary `{tag}` (MI355X, bench.py workload {_wl}: experiment / model / graphs / neighbours)', '']
 if bench:
     lines += [f"bench line of the traced run: {bench['value']:.2f} rollout-steps/s, {bench['ms_per_step']:.2f} ms/step; "
               f"edge_mlp avg launch {bench['roofline']['avg_launch_ms']:.3f} ms (HIP events) -> "
@@ -64,7 +67,7 @@ for k in sorted(set(fetch) | set(write)):
     traffic[short] = {'fetch_kib_raw': fm, 'write_kib': wm, 'read_bytes': rb, 'write_bytes': wb, 'hbm_bytes_per_launch': rb + wb}
     lines.append(f'| `{short}` | {len(fetch.get(k, []))} | {fm:.0f} | {rb:.3e} | {wm:.0f} | {wb:.3e} | {rb + wb:.3e} |')
 open(os.path.join(dst, f'{tag}_summary.md'), 'w').write('\n'.join(lines) + '\n')
-if traffic:
+if traffic and not KEEP_TRAFFIC_JSON:
     # stamp: bench.py reports `roofline.traffic` only when the kernel sources, the workload and the matrix path are the ones
     # these counters were taken on (no silent staleness)
     sys.path.insert(0, ROOT)
