@@ -52,9 +52,10 @@ extern "C" {
 
 typedef void* msmp_stream_t;
 
-/* ABI version: 300 = round 3 (msmp_last_status, msmp_tiles_t checked on every entry point that takes one).  Bumped whenever a
+/* ABI version: 400 = round 4 (msmp_tiles_t: listed, period_tiles, period_nodes; msmp_build_tiles writes 3 statistics);
+ * 300 = round 3 (msmp_last_status, msmp_tiles_t checked on every entry point that takes one).  Bumped whenever a
  * prototype or a blob layout changes; the ctypes host refuses a library whose version is not the one it was written for. */
-#define MSMP_ABI_VERSION 300
+#define MSMP_ABI_VERSION 400
 int msmp_version(void);
 const char* msmp_last_error(void);
 
@@ -202,10 +203,20 @@ typedef struct {
                                   * no list lookup); lo count = -1 otherwise */
     const int32_t* edge_slot;    /* [n_tiles][MSMP_TILE_EDGES]: lane 32 g + k = k-th in-edge (CSR order) of wave group g: target slot | source slot << 8;
                                   * 0 at lanes without an edge */
+    int32_t listed;              /* != 0: some tile is not "ranged" (msmp_build_tiles' stats[2] > 0): the kernels read every slot's node
+                                  * from tile_node; 0: they compute it from tile_halo and never touch the list */
+    int32_t period_tiles;        /* 0: the arrays above describe all n_tiles tiles of the batch.  > 0 (ABI 400): the batch is
+                                  * n_nodes / period_nodes copies of ONE pattern (the reference's batches: the same grid for every
+                                  * sample, common/utils.py:364-380), the arrays hold the period_tiles tiles of one copy (built from
+                                  * its CSR, node ids 0 .. period_nodes - 1; tile_nodes need not divide period_nodes: the last tile of
+                                  * a copy is short, so no tile straddles two graphs) and tile t of the launch uses entry
+                                  * t mod period_tiles with node ids shifted by (t div period_tiles) * period_nodes.  n_tiles is still the
+                                  * launch's tile count.  rowptr passed beside such a descriptor is the whole batch's. */
+    int32_t period_nodes;
 } msmp_tiles_t;
-/* stats_out (device, 2 x int32): largest node list, largest edge count of a wave group over the tiles (lists longer than
+/* stats_out (device, 3 x int32): largest node list, largest edge count of a wave group over the tiles (lists longer than
  * MSMP_TILE_NCAP are truncated in the output, groups of more than 32 edges cut: the structure is then not usable with this
- * group_nodes). */
+ * group_nodes), number of tiles that are not ranged (-> msmp_tiles_t.listed). */
 int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, int64_t n_edges, int group_nodes,
                      int32_t* tile_node_out, int32_t* tile_count_out, int32_t* tile_halo_out, int32_t* edge_slot_out,
                      int32_t* stats_out, msmp_stream_t stream);

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get('MSMP_LIB_PATH') or os.path.join(PKG, 'libmsmp_pde.so'
 class MsmpTiles(ctypes.Structure):
     """msmp_tiles_t (include/msmp_pde.h): node tiles of the LDS-staged message kernel."""
     _fields_ = [('tile_nodes', ctypes.c_int32), ('group_nodes', ctypes.c_int32), ('n_tiles', ctypes.c_int32), ('tile_node', c_void_p), ('tile_count', c_void_p),
-                ('tile_halo', c_void_p), ('edge_slot', c_void_p)]
+                ('tile_halo', c_void_p), ('edge_slot', c_void_p), ('listed', ctypes.c_int32), ('period_tiles', ctypes.c_int32), ('period_nodes', ctypes.c_int32)]
 
 
 MSMP_TILE_NCAP = 32
@@ -21,7 +21,7 @@ MSMP_LAYER_LIN = 1
 MSMP_ERR_UNSUPPORTED = -2
 MSMP_MAX_VARS = 8
 HIDDEN = 128
-MSMP_ABI_VERSION = 300          # include/msmp_pde.h: the library must report exactly this (argument lists changed in rounds 2 and 3)
+MSMP_ABI_VERSION = 400          # include/msmp_pde.h: the library must report exactly this (msmp_tiles_t grew in round 4)
 MSMP_STATUS_INPUT_RANGE, MSMP_STATUS_NODE_SATURATED, MSMP_STATUS_NONFINITE = 1, 2, 4
 
 # name -> (restype, argtypes); must list every symbol include/msmp_pde.h declares
@@ -211,17 +211,36 @@ def last_status(reset=False):
 
 
 def status_check():
-    """Called at the top of every solver forward: one host read.  New flags -> MsmpRangeWarning (MSMP_STRICT_RANGE=1 in the
-    environment: MsmpError).  The flags stay set until last_status(reset=True)."""
+    """One host read of the sticky flags.  New flags -> MsmpRangeWarning (MSMP_STRICT_RANGE=1 in the environment: MsmpError).
+    The flags stay set until last_status(reset=True).  Solver.forward no longer stops at the warning: see solvers._SolverBase.forward
+    (range_policy) -- a flagged forward is evaluated again on the exact-fp32 kernels."""
     flags = last_status()
     new = flags & ~_status_seen[0]
     if new:
         _status_seen[0] |= new
-        msg = ('msmp_pde_amd: the fp16-split matrix path left its range: ' + '; '.join(t for b, t in _STATUS_TEXT.items() if new & b)
-               + ".  Outputs since then are saturated / not finite.  Rescale the data or select the exact-fp32 kernels with "
-                 "lib().msmp_tune(b'split', 0); clear with last_status(reset=True).")
-        if os.environ.get('MSMP_STRICT_RANGE') == '1':
-            raise MsmpError(msg)
-        import warnings
-        warnings.warn(msg, MsmpRangeWarning, stacklevel=3)
+        _range_report(new, "Outputs since then are saturated / not finite.  Rescale the data or select the exact-fp32 kernels with "
+                           "lib().msmp_tune(b'split', 0); clear with last_status(reset=True).")
     return flags
+
+
+def _range_report(flags, what_now):
+    msg = ('msmp_pde_amd: the fp16-split matrix path left its range: ' + '; '.join(t for b, t in _STATUS_TEXT.items() if flags & b)
+           + '.  ' + what_now)
+    if os.environ.get('MSMP_STRICT_RANGE') == '1':
+        raise MsmpError(msg)
+    import warnings
+    warnings.warn(msg, MsmpRangeWarning, stacklevel=4)
+
+
+class exact_fp32:
+    """Context manager: the kernels launched inside use the exact-fp32 MFMA path (msmp_tune("split", 0): no input-range limit,
+    about 2x slower), whatever the process-wide setting is; restored on exit."""
+
+    def __enter__(self):
+        self._old = lib().msmp_tune_query(b'split')
+        lib().msmp_tune(b'split', 0)
+        return self
+
+    def __exit__(self, *exc):
+        lib().msmp_tune(b'split', self._old)
+        return False

@@ -469,7 +469,7 @@ extern "C" int msmp_scatter_mean_f32(const float* msg, const int32_t* rowptr, in
     MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31), MSMP_ERR_ARG, "msmp_scatter_mean_f32: bad n_nodes");
     const unsigned grid = (unsigned)((n_nodes + 7) / 8);
     timing_begin(MSMP_K_SCATTER_MEAN, (hipStream_t)stream);
-    hipLaunchKernelGGL(scatter_mean_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, msg, rowptr, (long)n_nodes, agg_out, status_ptr());
+    hipLaunchKernelGGL(scatter_mean_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, msg, rowptr, (long)n_nodes, agg_out, msmp_tune_get("split") ? status_ptr() : nullptr);
     timing_end(MSMP_K_SCATTER_MEAN, (hipStream_t)stream);
     return check_launch("scatter_mean_kernel");
 }
@@ -534,9 +534,7 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
     MSMP_REQUIRE(h && u && pos && vars && rowptr && col && tgt && graph_ptr && packed_main && h_out && workspace,
                  MSMP_ERR_ARG, "msmp_mp_layer_f32: null pointer");
     MSMP_REQUIRE(h_out != h, MSMP_ERR_ARG, "msmp_mp_layer_f32: h_out may not alias h");
-    MSMP_REQUIRE(!tiles || (tiles->tile_nodes >= 1 && (int64_t)tiles->n_tiles * tiles->tile_nodes >= n_nodes &&
-                            (int64_t)(tiles->n_tiles - 1) * tiles->tile_nodes < n_nodes),
-                 MSMP_ERR_ARG, "msmp_mp_layer_f32: tile descriptor does not cover %ld nodes", (long)n_nodes);
+    MSMP_REQUIRE(!tiles || msmp_tiles_ok(tiles, n_nodes), MSMP_ERR_ARG, "msmp_mp_layer_f32: tile descriptor does not cover %ld nodes", (long)n_nodes);
     const int gated = packed_gate != nullptr;
     const bool dense = (mode & MSMP_LAYER_DENSE_MESSAGE) != 0;
     mode &= ~MSMP_LAYER_DENSE_MESSAGE;

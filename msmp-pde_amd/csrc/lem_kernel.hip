@@ -1025,6 +1025,363 @@ __global__ __launch_bounds__(512) void lem_encoder_ws3_kernel(LemWsArgs a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// WEIGHT-STATIONARY, ONE WAVE PER SIMD edition (round 4; msmp_tune("lem", 5)).  The issue-port measurements of round 3
+// (scripts/micro/mfma_valu_overlap.hip) say what overlaps on a SIMD: a wave's OWN vector instructions issued between its MFMAs are
+// free, vector and matrix work of DIFFERENT waves add up.  The anti-phased kernel above pairs a matrix half of one wave with a
+// vector half of the other wave of the SIMD -- the sum, 2 150-2 400 clocks per slot for 1 600 clocks of MFMAs.  Here a workgroup
+// is FOUR waves, one per SIMD, with the whole register file each (512 registers: all four gate blocks of the wave's 32 channels,
+// 256 registers of stationary weights, live in it), every wave plays both roles for its channel slice, and a wave's matrix work of
+// one node tile is interleaved IN PROGRAM ORDER with its vector work of the other tile.  Two tiles (64 nodes) per workgroup, four
+// fused phases per time step, one barrier per phase:
+//     phase 0:  M_A(0,t)  ||  V_B(1,t-1)        M_A(X,t): g2, g3 of tile X from y_X(t)            (50 MFMAs)
+//     phase 1:  M_A(1,t)  ||  V_A(0,t)          V_A(X,t): z_X <- z + dt s(g2)(tanh(g3) - z), published as hi/lo fragments
+//     phase 2:  M_B(0,t)  ||  V_A(1,t)          M_B(X,t): g1 from y_X(t), lin from z_X(t+1)       (50 MFMAs)
+//     phase 3:  M_B(1,t)  ||  V_B(0,t)          V_B(X,t): y_X <- y + dt s(g1)(tanh(lin) - y), published
+// Every fragment area's last reader precedes its next writer by a barrier (y_0: read in phases 0 and 2, written in 3; y_1: read
+// in 1 and 3, written in 0; z_0: read in 2, written in 1; z_1: read in 3, written in 2), so one buffer per tile and state.
+// The chain M_A -> V_A -> M_B -> V_B of a tile is four phases, two tiles offset by one phase keep the matrix pipe fed in every
+// phase: 4 x 50 MFMAs per step and wave = the MFMA-bound 6.4 k clocks if the vector work hides (264 issue slots of the ~300 behind
+// 50 MFMAs).  Same per-value arithmetic as the other weight-stationary editions: a tile's result does not depend on the edition.
+// ----------------------------------------------------------------------------------------------
+// acc += W B with the stationary weight fragment read STRAIGHT from the accumulation registers (AGPRs): the 256 registers of weights
+// live there for the whole kernel, the 256 architectural registers hold states, accumulators and the vector work.  (Left to the
+// register allocator the weights end up in AGPRs as SPILL slots: four v_accvgpr_read per fragment in front of every MFMA.)
+// Inline asm is invisible to the hazard recogniser: B comes from LDS reads (waited for by the compiler), acc is read by vector
+// instructions only a whole phase (and a barrier) later, and consecutive MFMAs on one accumulator issue back to back.
+__device__ __forceinline__ void mfma_aw(f32x16& acc, const half8& w_agpr, const half8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_agpr), "v"(b));
+}
+// One value pair (r, r + 1) of a state update st <- st + dt s(a0) (tanh(a1) - st), cut into SIX pieces of 3-6 instructions, one
+// behind each MFMA of a K group (a dependent vector instruction issues ~8 clocks after its producer, a transcendental later still:
+// every piece only consumes what the previous piece -- a whole MFMA earlier -- produced).  Same operations in the same order as
+// lem_ws_update_publish_q: the same bits.
+struct LemPairTmp {
+    float ta[2], tb[2], ea[2], eb[2], qb[2], m[2], rr[2], d[2];
+    f32x2 sv;
+};
+template <int PIECE>
+__device__ __forceinline__ void lem_ws1_piece(const f32x16& a0, const f32x16& a1, int r, float c0, float c1, float idt, f32x16& st,
+                                              LemPairTmp& p, half8& phi, half8& plo, int j) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (PIECE == 0) {
+            p.ta[e] = a0[r + e] * c0;
+            p.tb[e] = vmin(a1[r + e] * c1, 60.f);
+        } else if (PIECE == 1) {
+            p.ea[e] = msmp_exp2(p.ta[e]);
+            p.eb[e] = msmp_exp2(p.tb[e]);
+        } else if (PIECE == 2) {
+            p.qb[e] = p.eb[e] + 1.0f;
+            p.m[e] = __builtin_fmaf(p.ea[e], idt, idt) * p.qb[e];
+        } else if (PIECE == 3) {
+            p.rr[e] = msmp_rcp(p.m[e]);
+            p.d[e] = 1.0f - p.eb[e];
+        } else if (PIECE == 4) {
+            p.sv[e] = __builtin_fmaf(p.rr[e], __builtin_fmaf(-st[r + e], p.qb[e], p.d[e]), st[r + e]);
+            st[r + e] = p.sv[e];
+        }
+    }
+    if (PIECE == 5) {
+        const half2 hp = __builtin_convertvector(p.sv, half2);
+        const half2 lp = split_lo_pair(hp, p.sv);
+        phi[j] = hp[0];
+        phi[j + 1] = hp[1];
+        plo[j] = lp[0];
+        plo[j + 1] = lp[1];
+    }
+}
+
+// One fused phase: (o0, o1) = input MFMAs + the two gate GEMMs over K = 128 of one tile;  beside them, when DO_V, the state update of
+// ANOTHER tile from (i0, i1) -- accumulators a previous phase produced -- and its publication.  Eight K groups of 6 MFMAs; behind
+// EVERY MFMA one piece of the group's value pair, pinned there with scheduling barriers (left alone the scheduler gathers the
+// vector instructions in front of three back-to-back MFMAs: measured 2.9 k clocks per phase instead of the MFMAs' 1.6 k).
+template <bool SAME, bool DO_V, int M>
+__device__ __forceinline__ void lem_ws1_phase(const half8 (&w0)[4][2][2], const half8 (&w1)[4][2][2], const half8* wx0, const half8* wx1,
+                                              const half8 (&bx)[M], const char* fb0, const char* fb1, f32x16& o0, f32x16& o1,
+                                              const f32x16& i0, const f32x16& i1, float c0, float c1, float idt, f32x16& st, char* pub) {
+    constexpr int FB = 64 * 16;       // bytes of one fragment plane
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    half8 h0 = *reinterpret_cast<const half8*>(fb0), l0 = *reinterpret_cast<const half8*>(fb0 + FB);
+    half8 h1 = h0, l1 = l0;
+    if (!SAME) {
+        h1 = *reinterpret_cast<const half8*>(fb1);
+        l1 = *reinterpret_cast<const half8*>(fb1 + FB);
+    }
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wx0[0], bx[0], zero, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wx1[0], bx[0], zero, 0, 0, 0);
+#pragma unroll
+    for (int m = 1; m < M; ++m) {
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wx0[m * 64], bx[m], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wx1[m * 64], bx[m], o1, 0, 0, 0);
+    }
+    half8 phi, plo;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int kt = g >> 1, s = g & 1;
+        const int r = 2 * g, j = 2 * (g & 3);      // the value pair (r, r + 1) of the update: half g >> 2, elements j, j + 1
+        LemPairTmp tmp;
+        half8 nh0 = h0, nl0 = l0, nh1 = h1, nl1 = l1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (MSMP_LOLO >= 2) mfma_aw(o0, w0[kt][s][1], l0);
+        mfma_aw(o0, w0[kt][s][1], h0);
+        if (g < 7) {                                // next group's fragments: requested behind this group's first MFMA
+            const int f = (g + 1) * 2;
+            nh0 = *reinterpret_cast<const half8*>(fb0 + f * FB);
+            nl0 = *reinterpret_cast<const half8*>(fb0 + (f + 1) * FB);
+            if (!SAME) {
+                nh1 = *reinterpret_cast<const half8*>(fb1 + f * FB);
+                nl1 = *reinterpret_cast<const half8*>(fb1 + (f + 1) * FB);
+            }
+        }
+        if (DO_V) lem_ws1_piece<0>(i0, i1, r, c0, c1, idt, st, tmp, phi, plo, j);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_aw(o0, w0[kt][s][0], l0);
+        if (DO_V) lem_ws1_piece<1>(i0, i1, r, c0, c1, idt, st, tmp, phi, plo, j);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_aw(o0, w0[kt][s][0], h0);
+        if (DO_V) lem_ws1_piece<2>(i0, i1, r, c0, c1, idt, st, tmp, phi, plo, j);
+        __builtin_amdgcn_sched_barrier(0);
+        if (MSMP_LOLO >= 2) mfma_aw(o1, w1[kt][s][1], l1);
+        mfma_aw(o1, w1[kt][s][1], h1);
+        if (DO_V) lem_ws1_piece<3>(i0, i1, r, c0, c1, idt, st, tmp, phi, plo, j);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_aw(o1, w1[kt][s][0], l1);
+        if (DO_V) lem_ws1_piece<4>(i0, i1, r, c0, c1, idt, st, tmp, phi, plo, j);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_aw(o1, w1[kt][s][0], h1);
+        if (DO_V) {
+            lem_ws1_piece<5>(i0, i1, r, c0, c1, idt, st, tmp, phi, plo, j);
+            if ((g & 3) == 3) {                     // a half tile (8 values) is complete: publish its hi / lo fragments
+                const int sv = g >> 2;
+                *reinterpret_cast<half8*>(pub + (sv * 2 + 0) * FB) = phi;
+                *reinterpret_cast<half8*>(pub + (sv * 2 + 1) * FB) = plo;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        h0 = nh0; l0 = nl0;
+        if (SAME) { h1 = nh0; l1 = nl0; } else { h1 = nh1; l1 = nl1; }
+    }
+}
+
+template <int P, int MODE>
+__global__ __launch_bounds__(256, 1) void lem_encoder_ws1_kernel(LemWsArgs a) {
+    constexpr int NS = (P + 1) / 2, M = (3 * P + 2 + 15) / 16;
+    // y fragments [tile 2] | z fragments [tile 2] (16 KB each) | scaled biases [512 + 256]
+    __shared__ __attribute__((aligned(16))) float lds[4 * SPLIT_CHUNK_FLOATS + 768];
+    __shared__ __attribute__((aligned(16))) float xconst[64 * 8];
+    __shared__ half8 wxl[4 * 4 * M * 64];               // input-column fragments: [wave 4][gate 4][m M][lane 64]
+    half8* const yfr = reinterpret_cast<half8*>(lds);
+    half8* const zfr = yfr + 2 * LEM_WS_FR;
+    float* const bias_l = lds + 4 * SPLIT_CHUNK_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const long n0 = (long)blockIdx.x * 64;
+    const bool two = n0 + 32 < a.n_nodes;              // (uniform) the second tile holds nodes
+    const float LOG2E = 1.44269504088896340736f;
+    const float inv_w = a.scales[4], inv_z = a.scales[5];
+    const int T = a.t_len;
+
+    {   // prologue: y(0) = 0 for both tiles, biases, per-node constants
+        half8 zero;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zero[j] = (_Float16)0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yfr[tid + 256 * i] = zero;
+        bias_l[tid] = a.bias_s[tid];
+        bias_l[256 + tid] = a.bias_s[256 + tid];
+        bias_l[512 + tid] = a.mlpb_s[tid];
+        if (MODE != 0 && tid < 64) {
+            const long nn = n0 + tid < a.n_nodes ? n0 + tid : a.n_nodes - 1;
+            float* row = xconst + 8 * tid;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) row[f] = 0.f;
+            row[0] = a.pos_x[nn];
+            if (MODE == 1) {
+                for (int f = 0; f < a.nv; ++f) row[2 + f] = a.vars[(size_t)nn * a.nv + f];
+            } else {
+                row[3] = a.pos_t[nn];
+                for (int f = 1; f < a.nv; ++f) row[3 + f] = a.vars[(size_t)nn * a.nv + f];
+            }
+        }
+    }
+    // stationary weights: the four gate blocks (rec_s order: g2, g3 | g1, lin) of this wave's 32 rows
+    half8 w[4][4][2][2];
+    half8* const wxw = wxl + (size_t)ks * (4 * M * 64) + lane;        // this wave's: [gate 4][m M][lane 64]
+    {
+        const half8* rs = reinterpret_cast<const half8*>(a.rec_s);
+        const half8* wh = reinterpret_cast<const half8*>(a.wx_h);
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        w[grp][kt][s][pl] = rs[(size_t)(grp * 4 + kt) * 1024 + ((s * 4 + ks) * 2 + pl) * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < M; ++m) wxw[(grp * M + m) * 64] = wh[((grp * 4 + ks) * 2 + m) * 64 + lane];
+        }
+    }
+    const float c0 = -inv_w * LOG2E, c1a = -2.0f * inv_w * LOG2E, c1b = -2.0f * inv_z * LOG2E, idt = 1.0f / a.dt;
+
+    f32x16 sz[2], sy[2];
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sz[X][r] = 0.f; sy[X][r] = 0.f; }
+    // per-lane byte addresses: fragment areas as B operands (read) and this wave's K tile of them (published)
+    constexpr int AREA = LEM_WS_FR * 16;
+    const char* const fy0 = reinterpret_cast<const char*>(yfr) + lane * 16;
+    const char* const fy1 = fy0 + AREA;
+    const char* const fz0 = reinterpret_cast<const char*>(zfr) + lane * 16;
+    const char* const fz1 = fz0 + AREA;
+    char* const py0 = reinterpret_cast<char*>(yfr) + lane * 16 + ks * (4 * 64 * 16);
+    char* const py1 = py0 + AREA;
+    char* const pz0 = reinterpret_cast<char*>(zfr) + lane * 16 + ks * (4 * 64 * 16);
+    char* const pz1 = pz0 + AREA;
+
+    // Step inputs: x_X(t) is requested a phase before its B fragments are formed (the loads fly behind that phase's MFMAs).
+    float xn0[2 * NS], xn1[2 * NS];
+    half8 bx0[M], bx1[M];
+    auto fetch0 = [&](int t) {
+        const long n = n0 + c;
+        lem_ws_load_x<P, MODE>(a, xconst + 8 * c, n < a.n_nodes ? n : a.n_nodes - 1, t, xn0);
+    };
+    auto fetch1 = [&](int t) {
+        const long n = n0 + 32 + c;
+        lem_ws_load_x<P, MODE>(a, xconst + 8 * (32 + c), n < a.n_nodes ? n : a.n_nodes - 1, t, xn1);
+    };
+    f32x16 a0, a1, b0, b1, c0a, c1acc, d0, d1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = a1[r] = b0[r] = b1[r] = c0a[r] = c1acc[r] = d0[r] = d1[r] = 0.f; }
+    __syncthreads();                    // the constants table and y(0) are read below
+    fetch0(0);
+    fetch1(0);
+    lem_ws_slots<P>(xn0, hh, bx0);
+    lem_ws_slots<P>(xn1, hh, bx1);
+
+    for (int t = 0; t < T; ++t) {
+        const int tn = t + 1 < T ? t + 1 : t;
+        // phase 0: M_A(0,t) || V_B(1,t-1)  (nothing to update before the first step)
+        if (t == 0) lem_ws1_phase<true, false, M>(w[0], w[1], wxw, wxw + M * 64, bx0, fy0, fy0, a0, a1, d0, d1, c0, c1b, idt, sy[1], py1);
+        else lem_ws1_phase<true, true, M>(w[0], w[1], wxw, wxw + M * 64, bx0, fy0, fy0, a0, a1, d0, d1, c0, c1b, idt, sy[1], py1);
+        __syncthreads();
+        // phase 1: M_A(1,t) || V_A(0,t)
+        lem_ws1_phase<true, true, M>(w[0], w[1], wxw, wxw + M * 64, bx1, fy1, fy1, b0, b1, a0, a1, c0, c1a, idt, sz[0], pz0);
+        __syncthreads();
+        // phase 2: M_B(0,t) || V_A(1,t); x_0(t+1) requested, its fragments formed behind the phase (the last use of x_0(t) is this phase's)
+        fetch0(tn);
+        lem_ws1_phase<false, true, M>(w[2], w[3], wxw + 2 * M * 64, wxw + 3 * M * 64, bx0, fy0, fz0, c0a, c1acc, b0, b1, c0, c1a, idt, sz[1], pz1);
+        lem_ws_slots<P>(xn0, hh, bx0);
+        __syncthreads();
+        // phase 3: M_B(1,t) || V_B(0,t); x_1(t+1) likewise
+        fetch1(tn);
+        lem_ws1_phase<false, true, M>(w[2], w[3], wxw + 2 * M * 64, wxw + 3 * M * 64, bx1, fy1, fz1, d0, d1, c0a, c1acc, c0, c1b, idt, sy[0], py0);
+        lem_ws_slots<P>(xn1, hh, bx1);
+        __syncthreads();
+    }
+    {   // V_B(1, T-1): the last update of tile 1
+        half8 phi, plo;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            LemPairTmp tmp;
+            lem_ws1_piece<0>(d0, d1, 2 * g, c0, c1b, idt, sy[1], tmp, phi, plo, 2 * (g & 3));
+            lem_ws1_piece<1>(d0, d1, 2 * g, c0, c1b, idt, sy[1], tmp, phi, plo, 2 * (g & 3));
+            lem_ws1_piece<2>(d0, d1, 2 * g, c0, c1b, idt, sy[1], tmp, phi, plo, 2 * (g & 3));
+            lem_ws1_piece<3>(d0, d1, 2 * g, c0, c1b, idt, sy[1], tmp, phi, plo, 2 * (g & 3));
+            lem_ws1_piece<4>(d0, d1, 2 * g, c0, c1b, idt, sy[1], tmp, phi, plo, 2 * (g & 3));
+            lem_ws1_piece<5>(d0, d1, 2 * g, c0, c1b, idt, sy[1], tmp, phi, plo, 2 * (g & 3));
+            if ((g & 3) == 3) {
+                *reinterpret_cast<half8*>(py1 + ((g >> 2) * 2 + 0) * 1024) = phi;
+                *reinterpret_cast<half8*>(py1 + ((g >> 2) * 2 + 1) * 1024) = plo;
+            }
+        }
+    }
+    __syncthreads();
+    // here: y_X(T) of both tiles is published in yfr; every wave holds its y slices in sy[]
+
+    if (a.with_mlp) {
+        const half8* ms = reinterpret_cast<const half8*>(a.mlp_s);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        w[gi][kt][s][pl] = ms[(size_t)(gi * 4 + kt) * 1024 + ((s * 4 + ks) * 2 + pl) * 64 + lane];
+        const float invA = a.scales[6], invB = a.scales[7];
+        // lemoutput_mlp on both tiles: Swish(Wa y + ba) published into the (dead) z areas, then Swish(Wb . + bb)
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            const half8* yb = yfr + X * LEM_WS_FR;
+            f32x16 acc;
+            lem_ws_bias(bias_l + 512 + 32 * ks, hh, acc);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const half8 h0 = yb[((kt * 2 + s) * 2 + 0) * 64 + lane], l0 = yb[((kt * 2 + s) * 2 + 1) * 64 + lane];
+                    MSMP_MFMA_LOLO(2, acc, w[0][kt][s][1], l0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][kt][s][1], h0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][kt][s][0], l0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][kt][s][0], h0, acc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = swishf(acc[r] * invA);
+            lem_ws_publish(acc, zfr + X * LEM_WS_FR, ks, lane);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            const half8* hb = zfr + X * LEM_WS_FR;
+            f32x16 res;
+            lem_ws_bias(bias_l + 512 + H + 32 * ks, hh, res);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const half8 h0 = hb[((kt * 2 + s) * 2 + 0) * 64 + lane], l0 = hb[((kt * 2 + s) * 2 + 1) * 64 + lane];
+                    MSMP_MFMA_LOLO(2, res, w[1][kt][s][1], l0);
+                    res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][1], h0, res, 0, 0, 0);
+                    res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][0], l0, res, 0, 0, 0);
+                    res = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][kt][s][0], h0, res, 0, 0, 0);
+                }
+            const long n = n0 + 32 * X + c;
+            if (n < a.n_nodes) {
+                float* o = a.out + (size_t)n * H + 32 * ks + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) v[m] = swishf(res[4 * q + m] * invB);
+                    *reinterpret_cast<f32x4*>(o + 8 * q) = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            const long n = n0 + 32 * X + c;
+            if (n < a.n_nodes) {
+                float* o = a.out + (size_t)n * H + 32 * ks + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) v[m] = sy[X][4 * q + m];
+                    *reinterpret_cast<f32x4*>(o + 8 * q) = v;
+                }
+            }
+        }
+    }
+    (void)two;
+}
+
 // fp32 chunks [128 out][32 k] (row-major, as `rec`) -> bf16x3 A fragments, acc order: thread = (chunk, s, T, lane)
 __global__ __launch_bounds__(256) void pack_lem_b3_kernel(const float* __restrict__ chunks, int n_chunks, float* __restrict__ out) {
     const int id = blockIdx.x * 256 + threadIdx.x;
@@ -1116,7 +1473,22 @@ extern "C" int msmp_lem_encoder_f32(const float* xin, int64_t n_nodes, int t_len
               packed + L.mlpb, h_out};
     const unsigned grid = (unsigned)((n_nodes + 127) / 128);
     timing_begin(MSMP_K_LEM, (hipStream_t)stream);
-    if (g_lem_split == 4) {
+    if (g_lem_split == 5) {
+        LemWsArgs wa{xin, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s,
+                     packed + L.mlp_s, packed + L.bias_s, packed + L.wx_h, packed + L.mlpb_s, packed + L.scales, h_out};
+        const unsigned g1 = (unsigned)((n_nodes + 63) / 64);
+        hipStream_t st = (hipStream_t)stream;
+        switch (ninp) {
+            case 1: hipLaunchKernelGGL((lem_encoder_ws1_kernel<1, 0>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 2: hipLaunchKernelGGL((lem_encoder_ws1_kernel<2, 0>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 3: hipLaunchKernelGGL((lem_encoder_ws1_kernel<3, 0>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 4: hipLaunchKernelGGL((lem_encoder_ws1_kernel<4, 0>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 5: hipLaunchKernelGGL((lem_encoder_ws1_kernel<5, 0>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 6: hipLaunchKernelGGL((lem_encoder_ws1_kernel<6, 0>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 7: hipLaunchKernelGGL((lem_encoder_ws1_kernel<7, 0>), dim3(g1), dim3(256), 0, st, wa); break;
+            default: hipLaunchKernelGGL((lem_encoder_ws1_kernel<8, 0>), dim3(g1), dim3(256), 0, st, wa); break;
+        }
+    } else if (g_lem_split == 4) {
         LemWsArgs wa{xin, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, (long)n_nodes, t_len, with_mlp, dt, packed + L.rec_s,
                      packed + L.mlp_s, packed + L.bias_s, packed + L.wx_h, packed + L.mlpb_s, packed + L.scales, h_out};
         const unsigned g96 = lem_partition(n_nodes, &wa.full_wgs);
@@ -1168,7 +1540,7 @@ extern "C" int msmp_lem_encoder_nodes_f32(const float* u, const float* pos_x, co
     MSMP_REQUIRE(n_nodes > 0 && n_nodes < (1L << 31) && tw >= 1 && nv >= 1, MSMP_ERR_ARG, "msmp_lem_encoder_nodes_f32: bad sizes");
     const int ninp = (two_d ? 3 : 2) + nv;
     MSMP_REQUIRE(ninp <= LEM_MAX_INP, MSMP_ERR_UNSUPPORTED, "msmp_lem_encoder_nodes_f32: ninp=%d > %d", ninp, LEM_MAX_INP);
-    MSMP_REQUIRE((g_lem_split == 3 || g_lem_split == 4) && g_lem_nodes, MSMP_ERR_UNSUPPORTED,
+    MSMP_REQUIRE((g_lem_split == 3 || g_lem_split == 4 || g_lem_split == 5) && g_lem_nodes, MSMP_ERR_UNSUPPORTED,
                  "msmp_lem_encoder_nodes_f32: only the weight-stationary editions (msmp_tune lem 3 / 4)");
     const LemLayout L = lem_layout();
     LemWsArgs wa{nullptr, u, pos_x, pos_t, vars, dt_cum, tw, nv, (long)n_nodes, tw, with_mlp, dt, packed + L.rec_s, packed + L.mlp_s,
@@ -1176,6 +1548,23 @@ extern "C" int msmp_lem_encoder_nodes_f32(const float* u, const float* pos_x, co
     const unsigned g64 = (unsigned)((n_nodes + 63) / 64), g96 = g_lem_split == 4 ? lem_partition(n_nodes, &wa.full_wgs) : 0u;
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_LEM, st);
+    if (g_lem_split == 5) {
+        const unsigned g1 = (unsigned)((n_nodes + 63) / 64);
+        if (!two_d) switch (ninp) {
+            case 3: hipLaunchKernelGGL((lem_encoder_ws1_kernel<3, 1>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 4: hipLaunchKernelGGL((lem_encoder_ws1_kernel<4, 1>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 5: hipLaunchKernelGGL((lem_encoder_ws1_kernel<5, 1>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 6: hipLaunchKernelGGL((lem_encoder_ws1_kernel<6, 1>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 7: hipLaunchKernelGGL((lem_encoder_ws1_kernel<7, 1>), dim3(g1), dim3(256), 0, st, wa); break;
+            default: hipLaunchKernelGGL((lem_encoder_ws1_kernel<8, 1>), dim3(g1), dim3(256), 0, st, wa); break;
+        } else switch (ninp) {
+            case 4: hipLaunchKernelGGL((lem_encoder_ws1_kernel<4, 2>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 5: hipLaunchKernelGGL((lem_encoder_ws1_kernel<5, 2>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 6: hipLaunchKernelGGL((lem_encoder_ws1_kernel<6, 2>), dim3(g1), dim3(256), 0, st, wa); break;
+            case 7: hipLaunchKernelGGL((lem_encoder_ws1_kernel<7, 2>), dim3(g1), dim3(256), 0, st, wa); break;
+            default: hipLaunchKernelGGL((lem_encoder_ws1_kernel<8, 2>), dim3(g1), dim3(256), 0, st, wa); break;
+        }
+    } else
     if (g_lem_split == 4) {
         if (!two_d) switch (ninp) {
             case 3: hipLaunchKernelGGL((lem_encoder_ws3_kernel<3, 1>), dim3(g96), dim3(512), 0, st, wa); break;

@@ -1302,6 +1302,8 @@ extern int g_lem_split;
 extern int g_lem_nodes;
 extern int g_lem_tail;
 extern int g_lem_share;
+// the sticky range status is the fp16-split path's: the exact-fp32 kernels have no range to leave (they run the data the split path could not)
+static int* split_status() { return msmp_tune_get("split") ? msmp::status_ptr() : nullptr; }
 static int g_split = 1;      // fp16-split matrix path (default); msmp_tune("split", 0) selects the fp32-MFMA kernels
 
 extern "C" int msmp_edge_mlp_f32(const float* h, const float* u, const float* pos, const float* vars,
@@ -1314,7 +1316,7 @@ extern "C" int msmp_edge_mlp_f32(const float* h, const float* u, const float* po
     if (n_edges == 0) return MSMP_OK;
     const PackedLayout L = packed_layout(tw, nv);
     EdgeArgs a{h, u, pos, vars, tgt, col, nullptr, (long)n_edges, (long)n_nodes, 0, 0, tw, nv, L.nc1,
-               packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, nullptr, nullptr, msg_out, nullptr, status_ptr()};
+               packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, nullptr, nullptr, msg_out, nullptr, split_status()};
     constexpr int NB = 2;
     const unsigned grid = (unsigned)((n_edges + 128 * NB - 1) / (128 * NB));
     timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
@@ -1347,6 +1349,7 @@ static int g_pair = 1;       // gated pair: both heads' projection / message ker
 constexpr int64_t PAIR_MAX_NODES = 65536;     // measured (E2, ms per rollout step, per-head vs paired): 256 graphs 1.33 / 1.14, 512: 2.06 / 1.95, 1024: 3.63 / 3.65, 2048: 6.95 / 7.07
 static int g_decoder = 1;     // 1-D decoder: 1 = eight lanes per node, split by position; 0 = one lane per node (decoder_kernel.hip)
 static int g_tile_arith = 1;  // ranged tiles: slot -> node arithmetically (tile_halo) instead of through the node list
+static int g_tile_align = 0;  // host layer: cut node tiles at graph boundaries also where tile_nodes does not divide the graph size (bitwise graph-order / sharding equivariance on knn graphs, ~11-20 % more tiles there)
 static int g_tile = 2;       // node tiles (tile_kernels.hip): 2 fold the projections into the message kernel, 1 staged P / Q rows, 0 off
 static int g_bwd_gemm = 1;   // layer backward: row GEMMs on rows_gemm_kernel (bf16x3 MFMA, fused epilogues); 0: rocblas_sgemm + separate passes
 static int g_tail = 1;       // fused node tail (msmp_node_tail_f32) inside msmp_mp_layer_f32; msmp_tune("tail", 0) chains the pieces
@@ -1357,6 +1360,7 @@ int msmp_tune_get(const char* key) {
     if (!strcmp(key, "pair")) return g_pair;
     if (!strcmp(key, "tile")) return g_tile;
     if (!strcmp(key, "tile_arith")) return g_tile_arith;
+    if (!strcmp(key, "tile_align")) return g_tile_align;
     if (!strcmp(key, "decoder")) return g_decoder;
     if (!strcmp(key, "lem_tail")) return g_lem_tail;
     if (!strcmp(key, "lem_share")) return g_lem_share;
@@ -1371,6 +1375,7 @@ extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "pair")) { g_pair = value; return MSMP_OK; }
     if (key && !strcmp(key, "tile")) { g_tile = value; return MSMP_OK; }
     if (key && !strcmp(key, "tile_arith")) { g_tile_arith = value; return MSMP_OK; }
+    if (key && !strcmp(key, "tile_align")) { g_tile_align = value; return MSMP_OK; }
     if (key && !strcmp(key, "decoder")) { g_decoder = value != 0; return MSMP_OK; }
     if (key && !strcmp(key, "lem_tail")) { g_lem_tail = value != 0; return MSMP_OK; }
     if (key && !strcmp(key, "lem_share") && value >= 1 && value <= 16) { g_lem_share = value; return MSMP_OK; }
@@ -1404,7 +1409,7 @@ static int edge_aggregate(const float* h, const float* u, const float* pos, cons
     int tile_nodes = max_in_degree > 0 ? edges_per_tile / max_in_degree : edges_per_tile;
     if (tile_nodes > 256) tile_nodes = 256;      // keeps the per-tile node loop short when degrees are tiny
     EdgeArgs a{h, u, pos, vars, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, 0, tw, nv, L.nc1,
-               packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, P, Q, nullptr, agg_out, status_ptr()};
+               packed + L.w1, packed + L.w2, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, P, Q, nullptr, agg_out, split_status()};
     const unsigned grid = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
     timing_begin(MSMP_K_EDGE_MLP, (hipStream_t)stream);
     if (P && edges_per_tile == 128 && g_split) hipLaunchKernelGGL((edge_mlp_kernel_occ2<1, true, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -1444,7 +1449,7 @@ int msmp_pair_project_aggregate(const float* h, const float* u, const float* pos
     for (int i = 0; i < 2; ++i)
         ea.head[i] = EdgeArgs{nullptr, nullptr, nullptr, nullptr, tgt, col, rowptr, (long)n_edges, (long)n_nodes, tile_nodes, 0, tw, nv, L.nc1,
                               packed[i] + L.w1, packed[i] + L.w2, packed[i] + L.w2s, packed[i] + L.scales, packed[i] + L.b1,
-                              packed[i] + L.b2, pp[i], qq[i], nullptr, agg[i], status_ptr()};
+                              packed[i] + L.b2, pp[i], qq[i], nullptr, agg[i], split_status()};
     timing_begin(MSMP_K_EDGE_MLP, st);
     hipLaunchKernelGGL(edge_mlp_pair_kernel_occ2, dim3((unsigned)((n_nodes + tile_nodes - 1) / tile_nodes), 2), dim3(256), 0, st, ea);
     timing_end(MSMP_K_EDGE_MLP, st);
@@ -1493,7 +1498,7 @@ extern "C" int msmp_node_tail_f32(const float* h, const float* agg_main, const f
     const float* pg = packed_gate ? packed_gate : packed_main;
     TailArgs a{h, {agg_main, agg_gate}, vars, graph_ptr, nv, mode, eps,
                {packed_main + L.b3, pg + L.b3}, {packed_main + L.b4, pg + L.b4}, {packed_main + L.w3vh, pg + L.w3vh},
-               {packed_main + L.w3s, pg + L.w3s}, {packed_main + L.w4t, pg + L.w4t}, {packed_main + L.scales, pg + L.scales}, out, status_ptr()};
+               {packed_main + L.w3s, pg + L.w3s}, {packed_main + L.w4t, pg + L.w4t}, {packed_main + L.scales, pg + L.scales}, out, split_status()};
     timing_begin(MSMP_K_NODE_UPDATE, (hipStream_t)stream);
     if (packed_gate) hipLaunchKernelGGL(node_tail_split_kernel<true>, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(node_tail_split_kernel<false>, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, a);

@@ -15,6 +15,8 @@ int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* 
                                    const msmp_tiles_t* tiles, int64_t n_nodes, int64_t n_edges, int tw, int nv, const float* packed_a,
                                    const float* packed_b, float* agg_a, float* agg_b, msmp_stream_t stream);   // tile_kernels.hip
 
+bool msmp_tiles_ok(const msmp_tiles_t* t, int64_t n_nodes);    // tile_kernels.hip: geometry of a caller-supplied tile descriptor
+
 namespace msmp {
 
 constexpr int H = MSMP_HIDDEN;          // hidden width

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(128) void build_tiles_kernel(const int* __restrict_
         tile_halo[4 * t + 2] = use ? s_halo[2] : 0;
         tile_halo[4 * t + 3] = use ? s_halo[3] : 0;
         atomicMax(&stats[0], total);
+        if (!use) atomicAdd(&stats[2], 1);                    // tiles that need the node list (not two runs): the launch then takes the LISTED kernels
     }
     if (kk == 0) atomicMax(&stats[1], ge1 - ge0);             // edges of one wave group: must fit 32 lanes
     // unused slots repeat the first node (valid addresses for unconditional loads): slots >= total were never written above
@@ -233,11 +234,12 @@ struct TileArgs {
     const float* Q;
     const int* rowptr;
     const int* tile_node;
-    const int* tile_count;
     const int* tile_halo;
     const int* edge_slot;
     long n_nodes, n_edges;
     int tile_nodes, group_nodes;      // group_nodes = tile_nodes / 4: targets of one wave
+    int period_tiles, period_nodes;   // > 0: the descriptor arrays hold ONE period (a graph); tile t uses entry t mod period_tiles, node ids + (t div period_tiles) period_nodes
+    unsigned period_magic;            // ceil(2^32 / period_tiles): t div period_tiles = umulhi(t, magic) (host checks n_tiles * period_tiles < 2^32)
     int tw, nv, nc1;
     const float* w1s;      // FOLD: nc1 split chunks, natural k order, fragment row (T, lane) = W1 row 32 T + lane
     const float* w2s;      // 4 split chunks (acc order)
@@ -250,12 +252,16 @@ struct TileArgs {
 
 // ------------------------------------------------------------------------------------------------------------------------
 // The tile body.  MODE 0: staged P / Q rows;  1: folded projections, features read from u / pos / vars;  2: folded, packed feature rows.
-// Cut for THREE workgroups per CU (50 176 B of LDS, <= 168 registers; round 2 measured 462 / 290 / 276 us per launch at the bench
-// size with one / two / three resident workgroups: the kernel is bound by the latency of a tile's dependent phases):
-//   * message_net_2's weights stream through LDS in HALF chunks (one K = 16 step: 8 KB), double-buffered: 2 x 8 KB;
+// LISTED: the structure has tiles whose halo is not two runs of consecutive nodes (knn on a scattered periodic grid): every slot's node
+// comes from the tile's node list (one batch of loads ahead of the row loads).  Otherwise the node of a slot is ARITHMETIC in four
+// integers of the tile (one 16-byte scalar load, cache-resident when the descriptor is periodic) and nothing is waited for ahead of
+// the row loads: round 3's single instantiation decided per tile with a uniform branch, and the compiler's conservative
+// s_waitcnt vmcnt(0) at each join serialised the four row loads of a thread behind each other and behind the weight prefetches
+// (six dependent memory round trips at the head of every tile; profiles/r04b_*).
+// Cut for THREE workgroups per CU (50 304 B of LDS, <= 168 registers):
+//   * message_net_2's weights stream through LDS in HALF chunks (one K = 16 step: 8 KB), double-buffered, by LDS-DMA;
 //   * the fp16 fragment tile of the folded projections overlays that buffer AND the head of the P / Q rows (dead until the
-//     projections are done: one barrier more than a private region would need);
-//   * the mean epilogue stages the messages in two rounds of 64 edges (33 KB), partial sums carried in registers in CSR order.
+//     projections are done: one barrier more than a private region would need).
 constexpr int WHALF_FLOATS = SPLIT_CHUNK_FLOATS / 2;                            // 8 KB: one K = 16 step of a split chunk
 constexpr int WBUF_FLOATS = 2 * WHALF_FLOATS;
 constexpr int TILE_MAIN_FLOATS = WBUF_FLOATS + 2 * TILE_NCAP * PQLD;      // 12 544 floats = 50 176 B
@@ -274,9 +280,32 @@ __device__ __forceinline__ void whalf_store(const WHalf& w, float* buf, int tid)
 #pragma unroll
     for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(buf + 4 * (tid + 256 * i)) = w.r[i];
 }
+// The same copy by LDS-DMA (global_load_lds_dwordx4: the lane-linear LDS image IS the fragment layout; no registers, no ds_write,
+// the workgroup barrier's vmcnt(0) waits for it).
+__device__ __forceinline__ void whalf_dma(const float* __restrict__ half_chunk, float* buf, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(half_chunk + 4 * (tid + 256 * i)),
+                                         (__attribute__((address_space(3))) void*)(buf + 4 * (tid + 256 * i)), 16, 0, 0);
+}
 
-template <int MODE>
-__device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, int n_tiles) {
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+using half4v = __attribute__((ext_vector_type(4))) _Float16;
+// hi = fp16(256 x), lo = fp16(256 x - hi) for a pair of node-row values: four mixed-precision FMAs (the scaling is exact, the
+// difference is formed exactly inside the FMA: the same bits as multiply / convert / convert back / subtract / convert, which took
+// eleven instructions with the saturating clamp round 3 had here).  No clamp: |x| >= 256 becomes an fp16 infinity, every product with
+// it is Inf / NaN, the aggregate of every target that reads the row is not finite and the epilogue raises the status word (and
+// Solver.forward evaluates the forward again on the exact-fp32 kernels) -- nothing saturates silently.
+__device__ __forceinline__ void split_node_pair(float x0, float x1, half2v& hi, half2v& lo) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo) : "v"(x0), "v"(x1), "s"(NODE_SCALE));
+}
+
+template <int MODE, bool LISTED>
+__device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
     constexpr bool FOLD = MODE != 0;
     float* wbuf = lds;                               // W2 half chunks (2 x 8 KB)
     float* pl = lds + WBUF_FLOATS;             // P rows [32][PQLD]
@@ -285,35 +314,41 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
     const int c = lane & 31, hh = lane >> 5;
     TPROF_DECL
     constexpr bool packed_feat = MODE == 2;
-    const int tile = blockIdx.x;
-    (void)n_tiles;
-    const int tile_n0 = tile * a.tile_nodes;
-    const int tile_n1 = (int)min((long)tile_n0 + a.tile_nodes, a.n_nodes);
-    const int* tnode = a.tile_node + (size_t)tile * TILE_NCAP;
-    int h_lo = 0, h_nlo = -1, h_hi = 0, h_nhi = 0;
-    if (a.tile_halo) { h_lo = a.tile_halo[4 * tile]; h_nlo = a.tile_halo[4 * tile + 1]; h_hi = a.tile_halo[4 * tile + 2]; h_nhi = a.tile_halo[4 * tile + 3]; }
+    // tile -> (descriptor entry, node offset): a periodic descriptor holds one graph's tiles
+    int tm = blockIdx.x, node_off = 0;
+    long n_end = a.n_nodes;
+    if (a.period_tiles > 0) {
+        const int q = a.period_tiles == 1 ? (int)blockIdx.x : (int)__umulhi((unsigned)blockIdx.x, a.period_magic);
+        tm = (int)blockIdx.x - q * a.period_tiles;
+        node_off = q * a.period_nodes;
+        n_end = (long)node_off + a.period_nodes;
+    }
+    const int tile_n0 = node_off + tm * a.tile_nodes;
+    const int tile_n1 = (int)min((long)tile_n0 + a.tile_nodes, n_end);
     const int nt_ = tile_n1 - tile_n0;
-    const bool listed = h_nlo < 0;                   // (uniform) not a ranged tile: slots through the node list
-    auto node_of = [&](int slot) -> int {            // branch-free on ranged tiles (three selects)
+    int h_lo = 0, h_nlo = 0, h_hi = 0, h_nhi = 0;
+    if (!LISTED) {                                   // one 16-byte scalar load
+        h_lo = a.tile_halo[4 * tm] + node_off; h_nlo = a.tile_halo[4 * tm + 1]; h_hi = a.tile_halo[4 * tm + 2] + node_off; h_nhi = a.tile_halo[4 * tm + 3];
+    }
+    auto node_of = [&](int slot) -> int {            // ranged tiles: targets | run below | run above | (unused slots: the first node)
         const int r = slot - nt_;
         int node = r < h_nlo + h_nhi ? h_hi + (r - h_nlo) : tile_n0;
         node = r < h_nlo ? h_lo + r : node;
         node = r < 0 ? tile_n0 + slot : node;
-        if (listed) node = tnode[slot];
         return node;
     };
 
     // slot pair of this lane's edge: stored per TILE ([tile][128], zero at lanes without an edge), so the load depends on nothing but
-    // the workgroup's index (not on rowptr: one memory round trip less on the tile's critical path)
-    const int sl = a.edge_slot[(size_t)tile * TILE_EDGES + wave * 32 + c];
+    // the workgroup's index
+    const int sl = a.edge_slot[(size_t)tm * TILE_EDGES + wave * 32 + c];
     // this wave's targets [gf, gl) and, for lane c < gl - gf, the lanes [er0, er0 + edeg) of this wave that hold target gf + c's in-edges
-    // (consumed by the mean at the very end: requested here, off the critical path)
+    // (consumed by the mean at the very end: requested here, off the critical path).  Only DIFFERENCES of rowptr are used, so a
+    // periodic structure reads its first period's entries (the same few cache lines for every tile of the launch).
     const int gf = min(tile_n0 + wave * a.group_nodes, tile_n1), gl = min(gf + a.group_nodes, tile_n1);
-    // (unconditional loads at a clamped index, the arithmetic deferred to the epilogue: inside a lane-masked block the compiler waits
-    // for the loads on the spot -- a memory round trip at the head of every tile's dependent chain)
-    const int rp_base = a.rowptr[__builtin_amdgcn_readfirstlane(gf)];      // wave-uniform: a scalar load
+    const int* rp = a.rowptr - node_off;
+    const int rp_base = rp[__builtin_amdgcn_readfirstlane(gf)];      // wave-uniform: a scalar load
     const int rp_row = gf + min(c, max(gl - gf - 1, 0));
-    int rp_lo = a.rowptr[rp_row], rp_hi = a.rowptr[rp_row + 1];
+    int rp_lo = rp[rp_row], rp_hi = rp[rp_row + 1];
     int er0 = 0, edeg = 0;
     auto edge_ranges = [&]() {           // called once the stage's own loads are out (and about to be waited for anyway)
         asm volatile("" : "+v"(rp_lo), "+v"(rp_hi));
@@ -329,6 +364,22 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
     const float* prow = pl + (sl & 255) * PQLD + 4 * hh;
     const float* qrow = ql + ((sl >> 8) & 255) * PQLD + 4 * hh;
 
+    // nodes of the slots this thread stages: rows (tid >> 5) + 8 i of h (or P / Q), row tid >> 3 of the feature columns
+    int rnode[4], fnode;
+    if (LISTED) {
+        const int* tnode = a.tile_node + (size_t)tm * TILE_NCAP;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rnode[i] = tnode[(tid >> 5) + 8 * i];
+        fnode = tnode[tid >> 3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rnode[i] += node_off;
+        fnode += node_off;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rnode[i] = node_of((tid >> 5) + 8 * i);
+        fnode = node_of(tid >> 3);
+    }
+
     WHalf ws;
     whalf_load(ws, a.w2s, tid);                      // W2 chunk 0, K step 0: stored once the buffer is free
 
@@ -337,10 +388,8 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         f32x4 pv[4], qv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int slot = (tid >> 5) + 8 * i;
-            const int node = node_of(slot);
-            pv[i] = *reinterpret_cast<const f32x4*>(a.P + (size_t)node * H + 4 * piece) * ACT_SCALE;
-            qv[i] = *reinterpret_cast<const f32x4*>(a.Q + (size_t)node * H + 4 * piece) * ACT_SCALE;
+            pv[i] = *reinterpret_cast<const f32x4*>(a.P + (size_t)rnode[i] * H + 4 * piece) * ACT_SCALE;
+            qv[i] = *reinterpret_cast<const f32x4*>(a.Q + (size_t)rnode[i] * H + 4 * piece) * ACT_SCALE;
         }
         edge_ranges();
 #pragma unroll
@@ -353,9 +402,8 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         __syncthreads();
         TPROF(0);
     } else {
-        // fragment tile: as in edge_tile_body, but at the START of the LDS (it overlays the weight buffer and the head of the P rows)
+        // fragment tile at the START of the LDS (it overlays the weight buffer and the head of the P rows)
         _Float16* bt = reinterpret_cast<_Float16*>(lds);
-        using half4 = __attribute__((ext_vector_type(4))) _Float16;
         const int ntail = a.nc1 - 8;
         unsigned woff = (unsigned)((wave * 2 * 64 + lane) * 16);
         asm volatile("" : "+v"(woff));
@@ -371,26 +419,17 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
 #pragma unroll
                 for (int p = 0; p < 2; ++p) { wp[i % 3][s][p] = wfrag(chp, s, p); wq[i % 3][s][p] = wfrag(chq, s, p); }
         };
-        wload(0);
-        wload(1);
         {
-            // Every slot's row through the branch-free slot -> node arithmetic: unconditional loads (lane-masked own / halo halves
-            // measured the same time with twice the instructions and 27 branches, round 3)
             f32x4 hv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = tid + 256 * i;
-                hv[i] = *reinterpret_cast<const f32x4*>(a.h + (size_t)node_of(idx >> 5) * H + 4 * (idx & 31));
-            }
-            const int tslot = tid >> 3;
+            for (int i = 0; i < 4; ++i) hv[i] = *reinterpret_cast<const f32x4*>(a.h + (size_t)rnode[i] * H + 4 * (tid & 31));
             const int g = tid & 7;
             float tx[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            const int tn = node_of(tslot);
             if (packed_feat) {
 #pragma unroll
                 for (int jc = 0; jc < 2; ++jc)
                     if (jc < ntail) {
-                        const f32x4 fv = *reinterpret_cast<const f32x4*>(a.feat + (size_t)tn * (32 * ntail) + 32 * jc + 4 * g);
+                        const f32x4 fv = *reinterpret_cast<const f32x4*>(a.feat + (size_t)fnode * (32 * ntail) + 32 * jc + 4 * g);
 #pragma unroll
                         for (int m = 0; m < 4; ++m) tx[jc][m] = fv[m];
                     }
@@ -401,70 +440,61 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
                             const int k = 32 * jc + 4 * g + m;
-                            const float uv = a.u[(size_t)tn * a.tw + min(k, a.tw - 1)];
-                            const float vv = a.vars[(size_t)tn * a.nv + min(max(k - a.tw - 1, 0), a.nv - 1)];
-                            tx[jc][m] = k < a.tw ? uv : (k == a.tw ? a.pos[tn] : (k <= a.tw + a.nv ? vv : 0.f));
+                            const float uv = a.u[(size_t)fnode * a.tw + min(k, a.tw - 1)];
+                            const float vv = a.vars[(size_t)fnode * a.nv + min(max(k - a.tw - 1, 0), a.nv - 1)];
+                            tx[jc][m] = k < a.tw ? uv : (k == a.tw ? a.pos[fnode] : (k <= a.tw + a.nv ? vv : 0.f));
                         }
                     }
             }
+            wload(0);                                // the projection's first two weight chunks: behind the row loads
+            wload(1);
             edge_ranges();
-            {       // range sentinel: node_scaled saturates silently (v_max3 drops NaN: a NaN row was flagged where it was produced)
-                float mx = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) mx = fmaxf(fmaxf(fmaxf(fabsf(hv[i][0]), fabsf(hv[i][1])), fmaxf(fabsf(hv[i][2]), fabsf(hv[i][3]))), mx);
-#pragma unroll
-                for (int jc = 0; jc < 2; ++jc) mx = fmaxf(fmaxf(fmaxf(fabsf(tx[jc][0]), fabsf(tx[jc][1])), fmaxf(fabsf(tx[jc][2]), fabsf(tx[jc][3]))), mx);
-                if (mx > NODE_RANGE) status_raise(a.status, MSMP_STATUS_NODE_SATURATED);
-            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int idx = tid + 256 * i;
-                half4 hi, lo;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const float xs = node_scaled(hv[i][m]);
-                    const _Float16 x = (_Float16)xs;
-                    hi[m] = x;
-                    lo[m] = (_Float16)(xs - (float)x);
-                }
-                const int piece = idx & 31;
-                _Float16* row = bt + ((piece >> 3) * 32 + (idx >> 5)) * BROW_T + 4 * (piece & 7);
-                *reinterpret_cast<half4*>(row) = hi;
-                *reinterpret_cast<half4*>(row + 32) = lo;
+                half2v h01, l01, h23, l23;
+                split_node_pair(hv[i][0], hv[i][1], h01, l01);
+                split_node_pair(hv[i][2], hv[i][3], h23, l23);
+                const int piece = tid & 31;
+                _Float16* row = bt + ((piece >> 3) * 32 + (tid >> 5) + 8 * i) * BROW_T + 4 * (piece & 7);
+                *reinterpret_cast<half4v*>(row) = half4v{h01[0], h01[1], h23[0], h23[1]};
+                *reinterpret_cast<half4v*>(row + 32) = half4v{l01[0], l01[1], l23[0], l23[1]};
             }
 #pragma unroll
             for (int jc = 0; jc < 2; ++jc) {
                 if (jc < ntail) {
-                    half4 phi, plo, qhi, qlo;
+                    // Q takes -(u, pos) and no variables: the fp16 halves of -x are the negated halves of x
+                    half2v ph[2], pl2[2], qh[2], ql2[2];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const int k = 32 * jc + 4 * g + m;
-                        const float xp = node_scaled(tx[jc][m]);
-                        const float xq = k <= a.tw ? -xp : 0.f;
-                        const _Float16 ph = (_Float16)xp, qh = (_Float16)xq;
-                        phi[m] = ph;
-                        plo[m] = (_Float16)(xp - (float)ph);
-                        qhi[m] = qh;
-                        qlo[m] = (_Float16)(xq - (float)qh);
+                    for (int m = 0; m < 2; ++m) {
+                        split_node_pair(tx[jc][2 * m], tx[jc][2 * m + 1], ph[m], pl2[m]);
+                        const int k = 32 * jc + 4 * g + 2 * m;
+                        const half2v nm = {(_Float16)(k <= a.tw ? -1.f : 0.f), (_Float16)(k + 1 <= a.tw ? -1.f : 0.f)};
+                        qh[m] = ph[m] * nm;
+                        ql2[m] = pl2[m] * nm;
                     }
-                    _Float16* rp = bt + ((4 + 2 * jc) * 32 + (tid >> 3)) * BROW_T + 4 * g;
-                    _Float16* rq = bt + ((5 + 2 * jc) * 32 + (tid >> 3)) * BROW_T + 4 * g;
-                    *reinterpret_cast<half4*>(rp) = phi;
-                    *reinterpret_cast<half4*>(rp + 32) = plo;
-                    *reinterpret_cast<half4*>(rq) = qhi;
-                    *reinterpret_cast<half4*>(rq + 32) = qlo;
+                    _Float16* rp_ = bt + ((4 + 2 * jc) * 32 + (tid >> 3)) * BROW_T + 4 * g;
+                    _Float16* rq_ = bt + ((5 + 2 * jc) * 32 + (tid >> 3)) * BROW_T + 4 * g;
+                    *reinterpret_cast<half4v*>(rp_) = half4v{ph[0][0], ph[0][1], ph[1][0], ph[1][1]};
+                    *reinterpret_cast<half4v*>(rp_ + 32) = half4v{pl2[0][0], pl2[0][1], pl2[1][0], pl2[1][1]};
+                    *reinterpret_cast<half4v*>(rq_) = half4v{qh[0][0], qh[0][1], qh[1][0], qh[1][1]};
+                    *reinterpret_cast<half4v*>(rq_ + 32) = half4v{ql2[0][0], ql2[0][1], ql2[1][0], ql2[1][1]};
                 }
             }
         }
         __syncthreads();
         TPROF(0);
 
-        const float sc = a.scales[0] * NODE_SCALE, inv = a.scales[4] * (ACT_SCALE / NODE_SCALE);
+        // Projections TRANSPOSED (weight fragments as the A operand, node fragments as B): D[channel 32 wave + acc_row(r, hh)][slot c],
+        // i.e. a lane holds four CONSECUTIVE channels of its slot per register quad: the P / Q rows go to LDS as 16-byte pieces
+        // (8 ds_write_b128; round 3: 32 ds_write_b32 + 32 multiplications) and keep the accumulators' scale 2^s 2^8, which the
+        // activation folds into its constants.
+        const float sc = a.scales[0] * NODE_SCALE;
         f32x16 accP, accQ;
-        {
-            const float bv = a.b1[32 * wave + c] * sc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { accP[r] = bv; accQ[r] = 0.f; }
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b1 + 32 * wave + 8 * q + 4 * hh);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { accP[4 * q + m] = bv[m] * sc; accQ[4 * q + m] = 0.f; }
         }
         auto afrag = [&](int ch, half8 (&ahi)[2], half8 (&alo)[2]) {
             const _Float16* row = bt + (ch * 32 + c) * BROW_T + 8 * hh;
@@ -475,10 +505,10 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
             }
         };
         auto mma3 = [&](f32x16& acc, const half8& ahi, const half8& alo, const half8& whi, const half8& wlo) {
-            MSMP_MFMA_LOLO(2, acc, alo, wlo);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wlo, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, whi, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi, acc, 0, 0, 0);
+            MSMP_MFMA_LOLO(2, acc, wlo, alo);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, ahi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, alo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, ahi, acc, 0, 0, 0);
         };
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
@@ -506,18 +536,17 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         TPROF(1);
         __syncthreads();                             // every wave is done with the fragment tile: the P / Q rows and the weight buffer may be written
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int slot = acc_row(r, hh);
-            pl[slot * PQLD + 32 * wave + c] = accP[r] * inv;
-            ql[slot * PQLD + 32 * wave + c] = accQ[r] * inv;
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<f32x4*>(pl + c * PQLD + 32 * wave + 8 * q + 4 * hh) = f32x4{accP[4 * q], accP[4 * q + 1], accP[4 * q + 2], accP[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(ql + c * PQLD + 32 * wave + 8 * q + 4 * hh) = f32x4{accQ[4 * q], accQ[4 * q + 1], accQ[4 * q + 2], accQ[4 * q + 3]};
         }
         whalf_store(ws, wbuf, tid);
         __syncthreads();
         TPROF(2);
     }
 
-    // ---- message_net_2 on Swish(P_i + Q_j): eight K = 16 steps u = 2 t + s; the matrix work of step u (12 MFMAs = 4 groups of 3)
-    // is interleaved with the activation of the same K step of the NEXT chunk (4 slices of two values), as in edge_tile_body.
+    // ---- message_net_2 on Swish(P_i + Q_j): eight K = 16 steps; the matrix work of step u (12 MFMAs = 4 groups of 3) is interleaved
+    // with the activation of the NEXT step's operand (4 slices of two values).
     // The GEMM is computed TRANSPOSED (the activation fragments are the A operand, the W2 fragments the B operand: both have the
     // same lane / k structure): y[T][r] = message_net_2 of edge acc_row(r, hh) of this wave, channel 32 T + c.  Registers 8 s .. 8 s + 7
     // of a tile are then exactly the B fragment of K step s of one more MFMA over the wave's 32 edges: the per-target sum.
@@ -540,14 +569,18 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
         }
     };
     float zt[8];
+    // the rows carry x_raw = g x64 (g = 2^s 2^8 / 2^6, a power of two; 1 for staged rows):  z = 64 Swish(x) = x_raw / (g (1 + e^-x))
+    const float act_g = FOLD ? a.scales[0] * (NODE_SCALE / ACT_SCALE) : 1.0f;
+    const float act_ct = (-1.44269504088896340736f / ACT_SCALE) / act_g;
     auto act_slice = [&](int i) {        // i = 0..3: piece j = i >> 1, elements 2 (i & 1), + 1
         const int j = i >> 1, m0 = 2 * (i & 1);
 #if MSMP_PRECISE_ACT
-        for (int m = m0; m < m0 + 2; ++m) zt[4 * j + m] = ACT_SCALE * swishf((pq[j][m] + pq[2 + j][m]) * (1.0f / ACT_SCALE));
+        for (int m = m0; m < m0 + 2; ++m) zt[4 * j + m] = ACT_SCALE * swishf((pq[j][m] + pq[2 + j][m]) * (1.0f / (ACT_SCALE * act_g)));
+        (void)act_ct;
 #else
         const f32x2 x = f32x2{pq[j][m0], pq[j][m0 + 1]} + f32x2{pq[2 + j][m0], pq[2 + j][m0 + 1]};
-        const f32x2 t = x * f32x2{-1.44269504088896340736f / ACT_SCALE, -1.44269504088896340736f / ACT_SCALE};
-        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+        const f32x2 t = x * f32x2{act_ct, act_ct};
+        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} * f32x2{act_g, act_g} + f32x2{act_g, act_g};
         const f32x2 z = x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
         zt[4 * j + m0] = z[0];
         zt[4 * j + m0 + 1] = z[1];
@@ -560,9 +593,11 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
     split8(zt, bhi[0], blo[0]);
     TPROF(3);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 7; ++u) {
         const int par = u & 1;
-        if (u < 7) whalf_load(ws, a.w2s + (size_t)(u + 1) * WHALF_FLOATS, tid);
+        // the next K step's weight half chunk by LDS-DMA into the buffer the previous step read (free since that step's barrier); the
+        // barrier at the end of this step waits for it
+        whalf_dma(a.w2s + (size_t)(u + 1) * WHALF_FLOATS, wbuf + (par ^ 1) * WHALF_FLOATS, tid);
         const half8* w = reinterpret_cast<const half8*>(wbuf + par * WHALF_FLOATS) + lane;
         half8 ahi[4], alo[4];
 #pragma unroll
@@ -570,7 +605,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
             ahi[T] = w[(T * 2 + 0) * 64];
             alo[T] = w[(T * 2 + 1) * 64];
         }
-        if (u < 7) gather_step((u + 1) >> 1, (u + 1) & 1);
+        gather_step((u + 1) >> 1, (u + 1) & 1);
 #pragma unroll
         for (int T = 2; T < 4; ++T) {
             ahi[T] = w[(T * 2 + 0) * 64];
@@ -584,86 +619,128 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
             y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blo[par], ahi[T], y[T], 0, 0, 0);
             y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[par], ahi[T], y[T], 0, 0, 0);
             TILE_SCHED_BARRIER();
-            if (u < 7) {
-                act_slice(T);
-                if (T == 3) split8(zt, bhi[par ^ 1], blo[par ^ 1]);
-                TILE_SCHED_BARRIER();
-            }
+            act_slice(T);
+            if (T == 3) split8(zt, bhi[par ^ 1], blo[par ^ 1]);
+            TILE_SCHED_BARRIER();
         }
         TPROF(4);
-        if (u < 7) {
-            whalf_store(ws, wbuf + (par ^ 1) * WHALF_FLOATS, tid);
-            __syncthreads();
-        }
+        __syncthreads();
         TPROF(5);
     }
 
-    // ---- mean over the in-edges of each target: one more MFMA per channel tile, wave-local (no LDS staging, no barrier) ----------------
-    // m64 = 64 Swish(y) in place.  The accumulators hold yy = 2^s 64 y; with kinv = 2^s:  m64 = yy / (kinv (1 + e^-y)).
-    {
-        const float kinv = a.scales[1];
-        const float inv2 = a.scales[5] * (1.0f / ACT_SCALE);
-#if MSMP_PRECISE_ACT
-        (void)kinv;
-#else
-        const float cexp = -1.44269504088896340736f * inv2;
-#endif
+    // ---- last K step, Swish of the messages and the per-target mean as one software pipeline over the channel tiles T: the vector
+    // work of tile T (Swish, fp16 split) is issued between the MFMAs of tile T + 1 (last K step) resp. of the means.  The mean of a
+    // target is one more MFMA: S[target row n][edge k] (0 / 1, exact in fp16) times the wave's message tile as fp16 hi + lo fragments
+    // straight from the accumulator registers, fp32 accumulation, then x 1 / (64 deg).  Same arithmetic in the same order per value
+    // as the straight-line form of round 3: bit-identical.
+    // m64 = 64 Swish(y).  The accumulators hold yy = 2^s 64 y; with kinv = 2^s:  m64 = yy / (kinv (1 + e^-y)).
+    const float kinv = a.scales[1];
+    const float inv2 = a.scales[5] * (1.0f / ACT_SCALE);
+    const float cexp = -1.44269504088896340736f * inv2;
+    auto swish2 = [&](int T, int r0, int r1) {
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
+        for (int r = r0; r < r1; r += 2) {
 #if MSMP_PRECISE_ACT
-                y[T][r] = ACT_SCALE * swishf(y[T][r] * inv2);
-                y[T][r + 1] = ACT_SCALE * swishf(y[T][r + 1] * inv2);
+            y[T][r] = ACT_SCALE * swishf(y[T][r] * inv2);
+            y[T][r + 1] = ACT_SCALE * swishf(y[T][r + 1] * inv2);
+            (void)kinv; (void)cexp;
 #else
-                const f32x2 yy = {y[T][r], y[T][r + 1]};
-                const f32x2 t = yy * f32x2{cexp, cexp};
-                const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                const f32x2 d = e * f32x2{kinv, kinv} + f32x2{kinv, kinv};
-                const f32x2 z = yy * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-                y[T][r] = z[0];
-                y[T][r + 1] = z[1];
+            const f32x2 yy = {y[T][r], y[T][r + 1]};
+            const f32x2 t = yy * f32x2{cexp, cexp};
+            const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            const f32x2 d = e * f32x2{kinv, kinv} + f32x2{kinv, kinv};
+            const f32x2 z = yy * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            y[T][r] = z[0];
+            y[T][r + 1] = z[1];
 #endif
-            }
-    }
-    TPROF(6);
-    // Selection matrix S[target row n][edge k] = 1 iff lane k of this wave holds an in-edge of target gf + n: the A operand, built
-    // from the lane's edge range as a bit mask; K index j of step s is edge 16 s + 8 (j >> 2) + 4 hh + (j & 3) (the accumulator's row order).
+        }
+    };
     half8 sf[2];
     {
-        const unsigned mask = edeg >= 32 ? 0xffffffffu : ((1u << edeg) - 1u) << (er0 & 31);
-        const char* lut = reinterpret_cast<const char*>(lds + TILE_MAIN_FLOATS);
-        using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+        constexpr int par = 1;
+        const half8* w = reinterpret_cast<const half8*>(wbuf + par * WHALF_FLOATS) + lane;
+        half8 ahi[4], alo[4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(lut + 8 * ((mask >> (16 * s + 4 * hh)) & 15u));
-            const u32x2 hi = *reinterpret_cast<const u32x2*>(lut + 8 * ((mask >> (16 * s + 8 + 4 * hh)) & 15u));
-            const u32x4 w = {lo[0], lo[1], hi[0], hi[1]};
-            sf[s] = __builtin_bit_cast(half8, w);
+        for (int T = 0; T < 4; ++T) {
+            ahi[T] = w[(T * 2 + 0) * 64];
+            alo[T] = w[(T * 2 + 1) * 64];
         }
+        TILE_SCHED_BARRIER();
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            MSMP_MFMA_LOLO(2, y[T], blo[par], alo[T]);
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[par], alo[T], y[T], 0, 0, 0);
+            TILE_SCHED_BARRIER();
+            if (T > 0) swish2(T - 1, 0, 6);
+            TILE_SCHED_BARRIER();
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blo[par], ahi[T], y[T], 0, 0, 0);
+            TILE_SCHED_BARRIER();
+            if (T > 0) swish2(T - 1, 6, 12);
+            TILE_SCHED_BARRIER();
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[par], ahi[T], y[T], 0, 0, 0);
+            TILE_SCHED_BARRIER();
+            if (T > 0) swish2(T - 1, 12, 16);
+            if (T == 0) {
+                // Selection matrix S[target row n][edge k] = 1 iff lane k of this wave holds an in-edge of target gf + n: the A operand,
+                // built from the lane's edge range as a bit mask through the nibble table; K index j of step s is edge
+                // 16 s + 8 (j >> 2) + 4 hh + (j & 3) (the accumulator's row order).
+                const unsigned mask = edeg >= 32 ? 0xffffffffu : ((1u << edeg) - 1u) << (er0 & 31);
+                const char* lut = reinterpret_cast<const char*>(lds + TILE_MAIN_FLOATS);
+                using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(lut + 8 * ((mask >> (16 * s + 4 * hh)) & 15u));
+                    const u32x2 hi = *reinterpret_cast<const u32x2*>(lut + 8 * ((mask >> (16 * s + 8 + 4 * hh)) & 15u));
+                    const u32x4 wv = {lo[0], lo[1], hi[0], hi[1]};
+                    sf[s] = __builtin_bit_cast(half8, wv);
+                }
+            }
+            TILE_SCHED_BARRIER();
+        }
+        TPROF(4);
     }
-    // 1 / (64 deg) per accumulator row: row n's factor sits in lane n; the accumulator rows of a lane are (r & 3) + 8 (r >> 2) + 4 hh
-    float* ftab = pl + wave * 32;            // the P rows are dead: every wave has passed the last barrier after its last gather
-    if (hh == 0) ftab[c] = (1.0f / ACT_SCALE) / (float)max(edeg, 1);
+    // 1 / (64 deg) per accumulator row: row n's factor sits in lane n; the accumulator rows of a lane are (r & 3) + 8 (r >> 2) + 4 hh.
+    // Through a per-wave table in the (dead) P rows: every wave has passed the last barrier after its last gather.
     f32x4 fr[4];
+    {
+        float* ftab = pl + wave * 32;
+        if (hh == 0) ftab[c] = (1.0f / ACT_SCALE) / (float)max(edeg, 1);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) fr[q] = *reinterpret_cast<const f32x4*>(ftab + 8 * q + 4 * hh);
-#pragma unroll
-    for (int T = 0; T < 4; ++T) {
+        for (int q = 0; q < 4; ++q) fr[q] = *reinterpret_cast<const f32x4*>(ftab + 8 * q + 4 * hh);
+    }
+    {
         half8 mh[2], ml[2];
+        auto splitT = [&](int T) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float v[8];
+            for (int s = 0; s < 2; ++s) {
+                float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = y[T][8 * s + j];
-            split8(v, mh[s], ml[s]);
-        }
+                for (int j = 0; j < 8; ++j) v[j] = y[T][8 * s + j];
+                split8(v, mh[s], ml[s]);
+            }
+        };
+        splitT(0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[T][r] = 0.f;
+        for (int T = 0; T < 4; ++T) {
+            const half8 h0 = mh[0], l0 = ml[0], h1 = mh[1], l1 = ml[1];
+            f32x16 z16;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf[s], ml[s], y[T], 0, 0, 0);
-            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf[s], mh[s], y[T], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) z16[r] = 0.f;
+            TILE_SCHED_BARRIER();
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf[0], l0, z16, 0, 0, 0);
+            TILE_SCHED_BARRIER();
+            if (T == 0) swish2(3, 0, 8);
+            TILE_SCHED_BARRIER();
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf[0], h0, y[T], 0, 0, 0);
+            TILE_SCHED_BARRIER();
+            if (T == 0) swish2(3, 8, 16);
+            TILE_SCHED_BARRIER();
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf[1], l1, y[T], 0, 0, 0);
+            TILE_SCHED_BARRIER();
+            if (T < 3) splitT(T + 1);
+            TILE_SCHED_BARRIER();
+            y[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sf[1], h1, y[T], 0, 0, 0);
+            TILE_SCHED_BARRIER();
         }
     }
     TPROF(7);
@@ -683,7 +760,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
                         for (int T = 0; T < 4; ++T) {
                             const float v = y[T][4 * q + m] * fr[q][m];
                             out[(size_t)row * H + 32 * T] = v;
-                            bad |= out_of_range(v);      // also NaN: an activation beyond fp16 upstream
+                            bad |= out_of_range(v);      // also NaN / Inf: a node row or an activation beyond fp16 upstream
                         }
                     }
                 }
@@ -695,10 +772,10 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds, in
     TPROF_FLUSH
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 3) void edge_tile_kernel(TileArgs a, int n_tiles) {
+template <int MODE, bool LISTED>
+__global__ __launch_bounds__(256, 3) void edge_tile_kernel(TileArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[TILE_LDS_FLOATS];
-    edge_tile_body<MODE>(a, lds, n_tiles);
+    edge_tile_body<MODE, LISTED>(a, lds);
 }
 
 // Both heads of a gated pair in ONE launch (blockIdx.y = head; same body, bit-identical results): small batches are bound by the
@@ -706,10 +783,10 @@ __global__ __launch_bounds__(256, 3) void edge_tile_kernel(TileArgs a, int n_til
 struct TileArgs2 {
     TileArgs head[2];
 };
-template <int MODE>
-__global__ __launch_bounds__(256, 3) void edge_tile_pair_kernel(TileArgs2 a, int n_tiles) {
+template <int MODE, bool LISTED>
+__global__ __launch_bounds__(256, 3) void edge_tile_pair_kernel(TileArgs2 a) {
     __shared__ __attribute__((aligned(16))) float lds[TILE_LDS_FLOATS];
-    edge_tile_body<MODE>(a.head[blockIdx.y], lds, n_tiles);
+    edge_tile_body<MODE, LISTED>(a.head[blockIdx.y], lds);
 }
 
 }  // namespace msmp
@@ -722,11 +799,6 @@ extern "C" __attribute__((visibility("default"))) int msmp_debug_prof_tile(unsig
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof_tile), 16 * sizeof(unsigned long long));
 }
 #endif
-
-// One tile per workgroup.  (Persistent workgroups, two per CU, that request the next tile's rows during the current tile's matrix
-// phase were built and measured in round 2: 6.81 vs 6.71 ms per rollout step, i.e. slower -- the dispatcher's own refill of a CU
-// as soon as a workgroup retires overlaps tiles better than a loop with a barrier at its end, and the prefetch registers spill.)
-static unsigned tile_grid(int n_tiles, int heads) { (void)heads; return (unsigned)n_tiles; }
 
 extern "C" int msmp_node_feature_stride(int tw, int nv) {
     if (tw <= 0 || nv < 1 || nv > MSMP_MAX_VARS) return -1;
@@ -774,7 +846,7 @@ extern "C" int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64
     MSMP_REQUIRE(group_nodes >= 1 && 4 * group_nodes <= MSMP_TILE_NCAP, MSMP_ERR_ARG, "msmp_build_tiles: group_nodes must be in 1..%d",
                  MSMP_TILE_NCAP / 4);
     hipStream_t st = (hipStream_t)stream;
-    const hipError_t me = hipMemsetAsync(stats_out, 0, 2 * sizeof(int32_t), st);
+    const hipError_t me = hipMemsetAsync(stats_out, 0, 3 * sizeof(int32_t), st);
     MSMP_REQUIRE(me == hipSuccess, MSMP_ERR_HIP, "msmp_build_tiles: memset: %s", hipGetErrorString(me));
     const int tile_nodes = 4 * group_nodes;
     const unsigned n_tiles = (unsigned)((n_nodes + tile_nodes - 1) / tile_nodes);
@@ -784,9 +856,37 @@ extern "C" int msmp_build_tiles(const int32_t* rowptr, const int32_t* col, int64
 }
 
 // a caller-supplied descriptor is trusted for its pointers only: its geometry must cover exactly n_nodes
-static bool tiles_ok(const msmp_tiles_t* t, int64_t n_nodes) {
-    return t->tile_node && t->tile_count && t->tile_halo && t->edge_slot && t->group_nodes >= 1 && t->tile_nodes == 4 * t->group_nodes &&
-           t->tile_nodes <= MSMP_TILE_NCAP && (int64_t)t->n_tiles * t->tile_nodes >= n_nodes && (int64_t)(t->n_tiles - 1) * t->tile_nodes < n_nodes;
+bool msmp_tiles_ok(const msmp_tiles_t* t, int64_t n_nodes) {
+    if (!(t->tile_node && t->tile_count && t->tile_halo && t->edge_slot && t->group_nodes >= 1 && t->tile_nodes == 4 * t->group_nodes &&
+          t->tile_nodes <= MSMP_TILE_NCAP && t->n_tiles >= 1))
+        return false;
+    if (t->period_tiles > 0) {       // one period's tiles, repeated: whole periods only, and the kernel's 32-bit division must hold
+        return t->period_nodes >= 1 && n_nodes % t->period_nodes == 0 && (int64_t)t->period_tiles * t->tile_nodes >= t->period_nodes &&
+               (int64_t)(t->period_tiles - 1) * t->tile_nodes < t->period_nodes && (int64_t)t->n_tiles == n_nodes / t->period_nodes * t->period_tiles &&
+               (int64_t)t->n_tiles * t->period_tiles < (1LL << 32);
+    }
+    return (int64_t)t->n_tiles * t->tile_nodes >= n_nodes && (int64_t)(t->n_tiles - 1) * t->tile_nodes < n_nodes;
+}
+
+static TileArgs tile_args(const float* h, const float* u, const float* pos, const float* vars, const float* feat, const float* p, const float* q,
+                          const int32_t* rowptr, const msmp_tiles_t* t, int64_t n_nodes, int64_t n_edges, int tw, int nv, const PackedLayout& L,
+                          const float* packed, float* agg) {
+    TileArgs a{};
+    a.h = h; a.u = u; a.pos = pos; a.vars = vars; a.feat = feat; a.P = p; a.Q = q; a.rowptr = rowptr;
+    a.tile_node = t->tile_node; a.tile_halo = t->tile_halo; a.edge_slot = t->edge_slot;
+    a.n_nodes = (long)n_nodes; a.n_edges = (long)n_edges; a.tile_nodes = t->tile_nodes; a.group_nodes = t->group_nodes;
+    a.period_tiles = t->period_tiles > 0 ? t->period_tiles : 0;
+    a.period_nodes = t->period_tiles > 0 ? t->period_nodes : 0;
+    a.period_magic = t->period_tiles > 1 ? (unsigned)(((1ULL << 32) + t->period_tiles - 1) / t->period_tiles) : 0u;
+    a.tw = tw; a.nv = nv; a.nc1 = L.nc1; a.w1s = packed + L.w1s; a.w2s = packed + L.w2s; a.scales = packed + L.scales; a.b1 = packed + L.b1;
+    a.b2 = packed + L.b2; a.agg = agg; a.status = status_ptr();      // (these kernels exist on the split path only)
+    return a;
+}
+
+template <int MODE>
+static void launch_tiles(const TileArgs& a, bool listed, unsigned n_tiles, hipStream_t st) {
+    if (listed) hipLaunchKernelGGL((edge_tile_kernel<MODE, true>), dim3(n_tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((edge_tile_kernel<MODE, false>), dim3(n_tiles), dim3(256), 0, st, a);
 }
 
 extern "C" int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, const float* pos, const float* vars, const float* feat,
@@ -797,20 +897,19 @@ extern "C" int msmp_edge_aggregate_tiled_f32(const float* h, const float* u, con
     MSMP_REQUIRE((p != nullptr) == (q != nullptr), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: give both of p, q or neither");
     const bool fold = p == nullptr;
     MSMP_REQUIRE(!fold || (h && u && pos && vars), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: null pointer (h, u, pos, vars)");
-    MSMP_REQUIRE(tiles_ok(tiles, n_nodes), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: the tile descriptor does not cover %ld nodes", (long)n_nodes);
+    MSMP_REQUIRE(msmp_tiles_ok(tiles, n_nodes), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: the tile descriptor does not cover %ld nodes", (long)n_nodes);
     MSMP_REQUIRE(n_nodes > 0 && n_edges >= 0 && n_nodes < (1L << 31) && n_edges < (1L << 31) && tw > 0 && nv >= 1 && nv <= MSMP_MAX_VARS,
                  MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_f32: bad sizes");
     MSMP_REQUIRE(msmp_tune_get("split"), MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_f32: only on the fp16-split matrix path");
     const PackedLayout L = packed_layout(tw, nv);
     MSMP_REQUIRE(!fold || L.nc1 - 8 <= 2, MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_f32: tw + 1 + nv <= 64");
-    TileArgs a{h, u, pos, vars, feat, p, q, rowptr, tiles->tile_node, tiles->tile_count, msmp_tune_get("tile_arith") ? tiles->tile_halo : nullptr, tiles->edge_slot, (long)n_nodes, (long)n_edges,
-               tiles->tile_nodes, tiles->group_nodes, tw, nv, L.nc1, packed + L.w1s, packed + L.w2s, packed + L.scales, packed + L.b1, packed + L.b2, agg_out, status_ptr()};
+    const TileArgs a = tile_args(h, u, pos, vars, feat, p, q, rowptr, tiles, n_nodes, n_edges, tw, nv, L, packed, agg_out);
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_EDGE_MLP, st);
-    const dim3 grid(tile_grid(tiles->n_tiles, 1));
-    if (fold && feat) hipLaunchKernelGGL(edge_tile_kernel<2>, grid, dim3(256), 0, st, a, (int)tiles->n_tiles);
-    else if (fold) hipLaunchKernelGGL(edge_tile_kernel<1>, grid, dim3(256), 0, st, a, (int)tiles->n_tiles);
-    else hipLaunchKernelGGL(edge_tile_kernel<0>, grid, dim3(256), 0, st, a, (int)tiles->n_tiles);
+    const bool listed = tiles->listed != 0 || !msmp_tune_get("tile_arith");
+    if (fold && feat) launch_tiles<2>(a, listed, (unsigned)tiles->n_tiles, st);
+    else if (fold) launch_tiles<1>(a, listed, (unsigned)tiles->n_tiles, st);
+    else launch_tiles<0>(a, listed, (unsigned)tiles->n_tiles, st);
     timing_end(MSMP_K_EDGE_MLP, st);
     return check_launch("edge_tile_kernel");
 }
@@ -821,21 +920,20 @@ int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* 
                                    const float* packed_b, float* agg_a, float* agg_b, msmp_stream_t stream) {
     MSMP_REQUIRE(h && u && pos && vars && rowptr && tiles && packed_a && packed_b && agg_a && agg_b, MSMP_ERR_ARG,
                  "msmp_edge_aggregate_tiled_pair: null pointer");
-    MSMP_REQUIRE(tiles_ok(tiles, n_nodes), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_pair: the tile descriptor does not cover %ld nodes", (long)n_nodes);
+    MSMP_REQUIRE(msmp_tiles_ok(tiles, n_nodes), MSMP_ERR_ARG, "msmp_edge_aggregate_tiled_pair: the tile descriptor does not cover %ld nodes", (long)n_nodes);
     const PackedLayout L = packed_layout(tw, nv);
     MSMP_REQUIRE(L.nc1 - 8 <= 2 && msmp_tune_get("split"), MSMP_ERR_UNSUPPORTED, "msmp_edge_aggregate_tiled_pair: unsupported configuration");
     TileArgs2 a2;
-    const float* packed[2] = {packed_a, packed_b};
-    float* agg[2] = {agg_a, agg_b};
-    for (int i = 0; i < 2; ++i)
-        a2.head[i] = TileArgs{h, u, pos, vars, feat, nullptr, nullptr, rowptr, tiles->tile_node, tiles->tile_count, msmp_tune_get("tile_arith") ? tiles->tile_halo : nullptr, tiles->edge_slot, (long)n_nodes,
-                              (long)n_edges, tiles->tile_nodes, tiles->group_nodes, tw, nv, L.nc1, packed[i] + L.w1s, packed[i] + L.w2s, packed[i] + L.scales,
-                              packed[i] + L.b1, packed[i] + L.b2, agg[i], status_ptr()};
+    a2.head[0] = tile_args(h, u, pos, vars, feat, nullptr, nullptr, rowptr, tiles, n_nodes, n_edges, tw, nv, L, packed_a, agg_a);
+    a2.head[1] = tile_args(h, u, pos, vars, feat, nullptr, nullptr, rowptr, tiles, n_nodes, n_edges, tw, nv, L, packed_b, agg_b);
     hipStream_t st = (hipStream_t)stream;
     timing_begin(MSMP_K_EDGE_MLP, st);
-    const dim3 grid(tile_grid(tiles->n_tiles, 2), 2);
-    if (feat) hipLaunchKernelGGL(edge_tile_pair_kernel<2>, grid, dim3(256), 0, st, a2, (int)tiles->n_tiles);
-    else hipLaunchKernelGGL(edge_tile_pair_kernel<1>, grid, dim3(256), 0, st, a2, (int)tiles->n_tiles);
+    const dim3 grid((unsigned)tiles->n_tiles, 2);
+    const bool listed = tiles->listed != 0 || !msmp_tune_get("tile_arith");
+    if (feat && listed) hipLaunchKernelGGL((edge_tile_pair_kernel<2, true>), grid, dim3(256), 0, st, a2);
+    else if (feat) hipLaunchKernelGGL((edge_tile_pair_kernel<2, false>), grid, dim3(256), 0, st, a2);
+    else if (listed) hipLaunchKernelGGL((edge_tile_pair_kernel<1, true>), grid, dim3(256), 0, st, a2);
+    else hipLaunchKernelGGL((edge_tile_pair_kernel<1, false>), grid, dim3(256), 0, st, a2);
     timing_end(MSMP_K_EDGE_MLP, st);
     return check_launch("edge_tile_pair_kernel");
 }

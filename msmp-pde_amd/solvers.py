@@ -292,25 +292,54 @@ class _SolverBase(nn.Module):
         tau = torch.tanh(_OutEdgeMean.apply((t[gs.col_long] - t[gs.tgt_long]) ** 2, gs))
         return (1.0 - tau) * h + tau * self.swish(mp_layer(h, u, pos_x, variables, gs, self.gnn_layers[i], None))
 
-    def _embed_hip(self, u, pos_x, variables):
-        """embedding_mlp as one HIP kernel (msmp_mlp2_swish_f32); the packed weights are cached per parameter version."""
+    def _embed_packed(self, dev):
+        """Packed embedding_mlp weights (msmp_pack_mlp2_f32), cached per parameter version; built on the CURRENT stream."""
         lin1, lin2 = self.embedding_mlp[0], self.embedding_mlp[2]
         ps = (lin1.weight, lin1.bias, lin2.weight, lin2.bias)
         key = (PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
-        L = lib()
-        k_in = lin1.in_features
         if getattr(self, '_embed_key', None) != key:
+            L = lib()
             f = [p.detach().to(torch.float32).contiguous() for p in ps]
-            blob = torch.empty(L.msmp_packed_mlp2_floats(k_in), dtype=torch.float32, device=u.device)
-            check(L.msmp_pack_mlp2_f32(*[ptr(t) for t in f], k_in, ptr(blob), current_stream()), 'msmp_pack_mlp2_f32')
+            blob = torch.empty(L.msmp_packed_mlp2_floats(lin1.in_features), dtype=torch.float32, device=dev)
+            check(L.msmp_pack_mlp2_f32(*[ptr(t) for t in f], lin1.in_features, ptr(blob), current_stream()), 'msmp_pack_mlp2_f32')
             self._embed_blob, self._embed_key = blob, key
+        return self._embed_blob
+
+    def _embed_hip(self, u, pos_x, variables):
+        """embedding_mlp as one HIP kernel (msmp_mlp2_swish_f32); the packed weights are cached per parameter version."""
+        L = lib()
+        k_in = self.embedding_mlp[0].in_features
+        blob = self._embed_packed(u.device)
         stride = L.msmp_mlp2_input_stride(k_in)
         pad = u.new_zeros(u.shape[0], stride - k_in)
         x = torch.cat((u, pos_x, variables, pad), -1).contiguous()
         assert x.shape[1] == stride
         out = torch.empty(u.shape[0], self.hidden_features, dtype=torch.float32, device=u.device)
-        check(L.msmp_mlp2_swish_f32(ptr(x), u.shape[0], k_in, ptr(self._embed_blob), ptr(out), current_stream()), 'msmp_mlp2_swish_f32')
+        check(L.msmp_mlp2_swish_f32(ptr(x), u.shape[0], k_in, ptr(blob), ptr(out), current_stream()), 'msmp_mlp2_swish_f32')
         return out
+
+    def _dt(self, dev):
+        """cumsum(dt) of the Euler update (models_gnn.py:275): constant until pde.dt changes; built on the CURRENT stream."""
+        dkey = (self.time_window, float(self.pde.dt), str(dev))
+        if getattr(self, '_dt_key', None) != dkey:
+            with torch.inference_mode(False):      # a plain tensor: an inference-mode tensor could not enter the autograd decoder later
+                self._dt_cum, self._dt_key = torch.cumsum(torch.ones(self.time_window, dtype=torch.float32, device=dev) * self.pde.dt, 0), dkey
+        return self._dt_cum
+
+    def warm_caches(self, dev=None):
+        """Build every lazily packed operand of an inference forward (layer blobs, encoder blobs, cumsum(dt)) on the CURRENT
+        stream.  Callers that evaluate one model on SEVERAL streams (sub_batches > 1, bench.SplitWorkload) call this first and
+        make the side streams wait for the current one: a cache is created by whichever stream gets there first, and the others
+        would read a blob whose pack kernels they never waited for."""
+        dev = dev or next(self.parameters()).device
+        for layers in (self.gnn_layers, getattr(self, 'gnn_layers_gate', ())):
+            for layer in layers:
+                layer.wide_weights() if layer.wide else layer.packed()
+        if self.LEM_ENCODER and not self.LSTM_ENCODER and self.hidden_features == 128 and not isinstance(self.embedding_lem, LEMS):
+            self.embedding_lem._pack(self.lemoutput_mlp)
+        elif not self.LEM_ENCODER and not self.LSTM_ENCODER:
+            self._embed_packed(dev)
+        self._dt(dev)
 
     # -- forward -------------------------------------------------------------------------------
     INPUT_RANGE = 255.0
@@ -341,11 +370,65 @@ class _SolverBase(nn.Module):
     # 6.56 -> 6.43 ms at 2048 (scripts/sub_batches.py).  Set on an instance (`model.sub_batches = 2`) or per class.
     sub_batches = 1
 
-    def forward(self, data):
-        _lib.status_check()       # range sentinel of the fp16-split path: one host read, warns once per new flag (no device sync)
-        if self.sub_batches > 1 and not torch.is_grad_enabled() and data.x.is_cuda and not torch.cuda.is_current_stream_capturing():
+    # What forward() does about the range of the default (fp16-split) matrix path, which carries node rows scaled by 2^8 in fp16
+    # (|x| <= 255) and activations scaled by 2^6 (|x| <= 1023) -- the reference has no such limit (models_gnn.py:1315-1377):
+    #   'auto' (default)  the FIRST forward of a model (and the first after load_state_dict) is followed by one stream
+    #                     synchronisation and a read of the sticky status word (msmp_last_status): if a kernel left the range,
+    #                     that forward is evaluated AGAIN on the exact-fp32 kernels (lib().msmp_tune(b'split', 0) for this model
+    #                     only) and the model stays on them, with one MsmpRangeWarning.  Later forwards read the word at entry
+    #                     without a synchronisation (flags raised by work that has completed since): same switch, from that call
+    #                     on -- the call whose kernels raised the flag has returned by then, and the warning says so.
+    #   'sync'            every forward is checked like the first one: no call ever returns an out-of-range result (one stream
+    #                     synchronisation per forward: ~1.5 % of a 2048-graph rollout step, more on small batches).
+    #   'warn'            round 3's behaviour: warn at the next forward, change nothing.
+    # Under autograd and during a hipGraph capture the synchronous check is skipped (entry check only).
+    range_policy = 'auto'
+    _range_exact = False          # this model runs on the exact-fp32 kernels
+    _range_probed = False         # the synchronous first-call check has been done
+
+    def _range_switch(self, flags, when):
+        self._range_exact = True
+        _lib._range_report(flags, f'{type(self).__name__}: {when}; this model now runs on the exact-fp32 MFMA kernels (no range limit, about 2x slower). '
+                                  'Rescale the data to keep the fast path; model._range_exact = False switches back.')
+        _lib.last_status(reset=True)
+
+    def _dispatch(self, data):
+        if self.sub_batches > 1 and not torch.is_grad_enabled() and data.x.is_cuda and not torch.cuda.is_current_stream_capturing() \
+                and not isinstance(getattr(self, 'embedding_lem', None), LEMS):
             return self._forward_sub_batches(data, int(self.sub_batches))
         return self._forward(data)
+
+    def forward(self, data):
+        policy = self.range_policy
+        if policy == 'warn' or not data.x.is_cuda or not lib().msmp_tune_query(b'split'):
+            _lib.status_check()
+            return self._dispatch(data)
+        if not self._range_exact:
+            flags = _lib.last_status()          # one host read, no device synchronisation
+            if flags:
+                self._range_switch(flags, 'raised by kernel work that completed before this call (an EARLIER result is saturated or not finite)')
+        if self._range_exact:
+            with _lib.exact_fp32():
+                return self._dispatch(data)
+        probe = (policy == 'sync' or not self._range_probed) and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()
+        stateful = isinstance(getattr(self, 'embedding_lem', None), LEMS)
+        states = self.embedding_lem.states if (probe and stateful) else None      # a second evaluation must start from the same carried states
+        out = self._dispatch(data)
+        if probe:
+            self._range_probed = True
+            torch.cuda.current_stream().synchronize()
+            flags = _lib.last_status()
+            if flags:
+                self._range_switch(flags, 'raised by this forward, which has been evaluated again')
+                if stateful:
+                    self.embedding_lem.states = states
+                with _lib.exact_fp32():
+                    out = self._dispatch(data)
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        self._range_probed = False          # new weights: check the first forward again
+        return super().load_state_dict(*args, **kwargs)
 
     def _sub_batch_plan(self, data, parts):
         """Per-structure split of `data` into `parts` contiguous blocks of graphs (dist.shard_graph: node rows are views, edges
@@ -377,6 +460,7 @@ class _SolverBase(nn.Module):
         lib().msmp_tune(b'lem_share', max(1, len(plan['subs'])))        # the sub-batches' LEM launches share the CUs (restored below)
         n = data.x.shape[0]
         cur = torch.cuda.current_stream()
+        self.warm_caches(data.x.device)      # shared blobs are packed HERE, on the caller's stream; every side stream waits for it below
         out = None
         per_node = [k for k, v in data.__dict__.items() if torch.is_tensor(v) and not k.startswith('_') and k not in ('edge_index', 'batch')
                     and v.dim() >= 1 and v.shape[0] == n]
@@ -413,11 +497,7 @@ class _SolverBase(nn.Module):
             pos_x, pos_t = pos_x.float(), pos_t.float()
             u = u_in.float().contiguous()
             feat = node_features(u, pos_x.reshape(-1).contiguous(), variables.contiguous()) if want_feat else None
-        dkey = (tw, float(self.pde.dt), str(u.device))
-        if getattr(self, '_dt_key', None) != dkey:       # cumsum(dt) of the Euler update: constant until pde.dt changes
-            with torch.inference_mode(False):      # a plain tensor: an inference-mode tensor could not enter the autograd decoder later
-                self._dt_cum, self._dt_key = torch.cumsum(torch.ones(tw, dtype=torch.float32, device=u.device) * self.pde.dt, 0), dkey
-        dt = self._dt_cum
+        dt = self._dt(u.device)
 
         h = self._encode(u, pos_x, pos_t, variables, dt)
         for i in range(self.hidden_layer):
@@ -519,7 +599,9 @@ class _GraphedForward:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                 # warm-up on a side stream: weight packing, workspaces, CSR build
                 for _ in range(2):
-                    model(self.data)
+                    # through _forward, like the capture below: with sub_batches > 1 the eager forward() would fan out over streams
+                    # that share this ONE private workspace (sized for a sub-batch) and the capture would then outgrow it
+                    model._forward(self.data)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()

@@ -391,7 +391,7 @@ def test_lem_encoder_kernel(mp, ninp, t_len, n):
         ys = lem.encode(xin, None)           # default: fp16-split matrix path, weight-stationary kernel
         hs = lem.encode(xin, mlp)
         older = {}
-        for variant in (3,):                # the two-tile weight-stationary kernel of round 2 (the streamed-weight editions are gone)
+        for variant in (3, 5):              # the two-tile weight-stationary kernel of round 2 and the one-wave-per-SIMD edition of round 4
             mp.lib().msmp_tune(b'lem', variant)
             older[variant] = (lem.encode(xin, None), lem.encode(xin, mlp))
         mp.lib().msmp_tune(b'split', 0)
@@ -416,6 +416,8 @@ def test_lem_encoder_kernel(mp, ninp, t_len, n):
     for variant, (yv, hv) in older.items():
         assert np.abs(yv.double().cpu().numpy() - ref_y).max() < 5e-6, variant
         assert np.abs(hv.double().cpu().numpy() - ref_h).max() < 5e-6, variant
+    # the weight-stationary editions evaluate the same per-value arithmetic in the same order: the same bits
+    assert torch.equal(older[5][0], ys) and torch.equal(older[5][1], hs)
 
 
 @pytest.mark.parametrize('n', [33, 96 * 256 + 32 * 5 + 7, 96 * 256, 96 * 256 + 1, 204800, 96 * 512 + 32 * 256 + 1])
@@ -597,9 +599,12 @@ def test_lem_encoder_in_kernel_input_assembly(mp, two_d, nv, tw, n):
         ref = lem.encode(xin.contiguous(), mlp)
         out = lem.encode_nodes(u, pos_x, pos_t, variables, dt, two_d, mlp)
         assert out is not None and torch.equal(out, ref)
-        mp.lib().msmp_tune(b'lem', 3)
         try:
-            assert torch.equal(lem.encode_nodes(u, pos_x, pos_t, variables, dt, two_d, mlp), lem.encode(xin.contiguous(), mlp))      # the two-tile edition too
+            for edition in (3, 5):          # the two-tile edition and the one-wave-per-SIMD edition too; every edition gives the same bits
+                mp.lib().msmp_tune(b'lem', edition)
+                o5 = lem.encode_nodes(u, pos_x, pos_t, variables, dt, two_d, mlp)
+                assert torch.equal(o5, lem.encode(xin.contiguous(), mlp)), edition
+                assert torch.equal(o5, ref), edition
         finally:
             mp.lib().msmp_tune(b'lem', 4)
 
@@ -711,11 +716,23 @@ def test_node_tiles_are_a_valid_cover(mp, exp, bsz, nx, neighbors):
     tn, gn, n_tiles = desc.tile_nodes, desc.group_nodes, desc.n_tiles
     assert tn == 4 * gn
     rowptr, col = gs.rowptr.cpu().numpy(), gs.col.cpu().numpy()[:gs.n_edges]
-    tile_node = tile_node.cpu().numpy().reshape(n_tiles, _lib.MSMP_TILE_NCAP)
-    tile_count, edge_slot = tile_count.cpu().numpy(), edge_slot.cpu().numpy().reshape(n_tiles, _lib.MSMP_TILE_EDGES)
-    assert n_tiles == -(-gs.n_nodes // tn)
-    for ti in range(n_tiles):
-        n0, n1 = ti * tn, min((ti + 1) * tn, gs.n_nodes)
+    # a PERIODIC descriptor (identical graphs whose size the tile divides, or msmp_tune("tile_align", 1)) holds the tiles of ONE graph,
+    # built from that graph's CSR in its own node ids; the launch repeats them with shifted ids
+    periodic = desc.period_tiles > 0
+    n_src = desc.period_nodes if periodic else gs.n_nodes
+    n_meta = desc.period_tiles if periodic else n_tiles
+    if periodic:
+        assert gs.n_nodes % n_src == 0 and n_tiles == n_meta * (gs.n_nodes // n_src) and n_meta == -(-n_src // tn)
+        eg = rowptr[n_src]
+        for k in range(1, gs.n_nodes // n_src):        # the claim the descriptor rests on: every graph is the first one, shifted
+            assert np.array_equal(rowptr[k * n_src:(k + 1) * n_src + 1] - k * eg, rowptr[:n_src + 1])
+            assert np.array_equal(col[k * eg:(k + 1) * eg] - k * n_src, col[:eg])
+    else:
+        assert n_tiles == -(-gs.n_nodes // tn)
+    tile_node = tile_node.cpu().numpy().reshape(n_meta, _lib.MSMP_TILE_NCAP)
+    tile_count, edge_slot = tile_count.cpu().numpy(), edge_slot.cpu().numpy().reshape(n_meta, _lib.MSMP_TILE_EDGES)
+    for ti in range(n_meta):
+        n0, n1 = ti * tn, min((ti + 1) * tn, n_src)
         e0, e1 = rowptr[n0], rowptr[n1]
         assert tile_count[ti] <= _lib.MSMP_TILE_NCAP
         nodes = tile_node[ti]
@@ -723,7 +740,7 @@ def test_node_tiles_are_a_valid_cover(mp, exp, bsz, nx, neighbors):
         extra = nodes[n1 - n0:tile_count[ti]]
         assert len(set(extra.tolist())) == len(extra) and not np.any((extra >= n0) & (extra < n1))
         assert set(extra.tolist()) == set(col[e0:e1][(col[e0:e1] < n0) | (col[e0:e1] >= n1)].tolist())
-        assert np.all((nodes >= 0) & (nodes < gs.n_nodes))
+        assert np.all((nodes >= 0) & (nodes < n_src))
         for g in range(4):
             gf = min(n0 + g * gn, n1)
             gl = min(gf + gn, n1)
@@ -738,9 +755,10 @@ def test_node_tiles_are_a_valid_cover(mp, exp, bsz, nx, neighbors):
         if nlo >= 0:        # ranged tile: the list is [targets | lo run | hi run], which the kernel reproduces arithmetically
             want = np.concatenate([np.arange(n0, n1), np.arange(lo, lo + nlo), np.arange(hi, hi + nhi)])
             assert np.array_equal(nodes[:tile_count[ti]], want)
+    assert bool(desc.listed) == bool((tile_halo[:, 1] < 0).any())
     if exp in ('E2', 'MSWG3', 'WE3'):
         assert (tile_halo[:, 1] >= 0).all(), 'every tile of a banded graph without wrap-around is ranged'
-    print(f'{exp}: {int((tile_halo[:, 1] >= 0).sum())} of {n_tiles} tiles ranged, tile_nodes {tn} (4 groups of {gn})')
+    print(f'{exp}: {int((tile_halo[:, 1] >= 0).sum())} of {n_meta} described tiles ranged, tile_nodes {tn} (4 groups of {gn}), periodic {periodic} ({n_tiles} tiles launched)')
 
 
 def test_irregular_graph_does_not_tile(mp):

@@ -182,41 +182,65 @@ def test_layer_error_growth(mp, kind, exp):
     assert max(fresh) <= 5e-7, fresh
 
 
-def test_graph_sharding_is_exact(mp):
-    """Multi-GPU row (e): graphs are independent, so a rank that evaluates a contiguous shard of the
-    batch gets the rows the whole-batch evaluation gives.  The HIP message-passing stack is bit-identical
-    under sharding (fixed per-item arithmetic order); the PyTorch encoder/decoder GEMMs may pick another
-    rocBLAS kernel for another row count, so the end-to-end comparison allows 5e-6."""
+@pytest.mark.parametrize('exp,align', [('E2', 0), ('MSWG3', 0), ('WE3', 1), ('RPU', 1), ('WE3', 0), ('RPU', 0)])
+def test_graph_sharding_is_exact(mp, exp, align):
+    """Multi-GPU row (e): graphs are independent, so a rank that evaluates a contiguous shard of the batch gets the rows the
+    whole-batch evaluation gives.  BITWISE for the message-passing stack wherever no node tile straddles two graphs: E2 / MSWG3
+    (tiles of 20 nodes divide the 100-node graphs: periodic descriptor) and, with msmp_tune("tile_align", 1), the knn configs
+    WE3 / RPU (BASELINE configs[2], [3]; tiles cut at the graph boundaries, 11-20 % more of them).  In their DEFAULT form the WE3 /
+    RPU tiles (28 / 22 nodes) straddle graphs, a target's messages then meet the mean's MFMA at other K positions in a shard than in
+    the whole batch, and the stack agrees to fp32 rounding only (stated and measured here, not claimed away).
+    The PyTorch encoder / decoder GEMMs may pick another rocBLAS kernel for another row count: end to end 5e-6."""
     from msmp_pde_amd.dist import shard_graph
     from msmp_pde_amd.graph import structure_of
-    torch.manual_seed(4)
-    case = synthetic_case(mp, 'E2', bsz=6, seed=5)
-    model = mp.MP_PDE_SolverGated(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=2).cuda().eval()
-    full_graph = case.graph.to('cuda')
-    nx = 100
-    n = full_graph.x.shape[0]
-    h = torch.randn(n, 128, device='cuda')
-    var = torch.rand(n, 2, device='cuda')
-    pos = (full_graph.pos[:, 1] / 16.0).float()
+    L = mp.lib()
+    L.msmp_tune(b'tile_align', align)
+    try:
+        torch.manual_seed(4)
+        case = synthetic_case(mp, exp, bsz=6, seed=5)
+        two_d = exp in ('RPU', 'MSWG3')
+        cls = mp.MP_PDE_Solver2DGated if two_d else mp.MP_PDE_SolverGated
+        model = cls(case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=2).cuda().eval()
+        full_graph = case.graph.to('cuda')
+        nx = 100
+        n = full_graph.x.shape[0]
+        nv = len(case.eqv) + 1
+        h = torch.randn(n, 128, device='cuda')
+        var = torch.rand(n, nv, device='cuda')
+        pos = (full_graph.pos[:, 1] / 16.0).float()
+        t = structure_of(full_graph).tiles()
+        no_straddle = t is None or t[0].period_tiles > 0
+        if t is not None:
+            assert no_straddle == (align == 1 or nx % t[0].tile_nodes == 0), (t[0].tile_nodes, t[0].period_tiles)
 
-    def stack(graph, sl):
-        gs = structure_of(graph)
-        hh = h[sl]
-        with torch.no_grad():
-            for i in range(2):
-                hh = mp.mp_layer(hh, graph.x.float(), pos[sl], var[sl], gs, model.gnn_layers[i], model.gnn_layers_gate[i])
-        return hh
+        def stack(graph, sl):
+            gs = structure_of(graph)
+            hh = h[sl]
+            with torch.no_grad():
+                for i in range(2):
+                    hh = mp.mp_layer(hh, graph.x.float(), pos[sl], var[sl], gs, model.gnn_layers[i], model.gnn_layers_gate[i])
+            return hh
 
-    with torch.no_grad():
-        full = model(full_graph)
-    full_h = stack(full_graph, slice(0, n))
-    for rank in range(3):
-        sh = shard_graph(case.graph, rank, 3).to('cuda')
-        sl = slice(rank * 2 * nx, (rank + 1) * 2 * nx)
-        assert torch.equal(stack(sh, sl), full_h[sl])
         with torch.no_grad():
-            part = model(sh)
-        assert (part - full[sl]).abs().max().item() < 5e-6
+            full = model(full_graph)
+        full_h = stack(full_graph, slice(0, n))
+        worst = 0.0
+        for rank in range(3):
+            sh = shard_graph(case.graph, rank, 3).to('cuda')
+            sl = slice(rank * 2 * nx, (rank + 1) * 2 * nx)
+            part_h = stack(sh, sl)
+            if no_straddle:
+                assert torch.equal(part_h, full_h[sl]), (exp, align, (part_h - full_h[sl]).abs().max().item())
+            else:       # two InstanceNorm-ed layers of order-one values: a rounding-order difference stays at a few ulp
+                worst = max(worst, (part_h - full_h[sl]).abs().max().item())
+                assert worst < 2e-5, worst
+            with torch.no_grad():
+                part = model(sh)
+            assert (part - full[sl]).abs().max().item() < (5e-6 if no_straddle else 2e-5)
+        print(f'{exp} tile_align={align}: tile_nodes {t[0].tile_nodes if t else None}, periodic {no_straddle}; shard vs whole batch '
+              + ('bitwise' if no_straddle else f'max |diff| {worst:.2e} (tiles straddle graphs)'))
+    finally:
+        L.msmp_tune(b'tile_align', 0)
 
 
 @pytest.mark.parametrize('name,exp', [('MSMP-PDE', 'E2'), ('Gated2D', 'MSWG3')])
@@ -478,49 +502,106 @@ def test_input_range_guard_and_exact_fp32_fallback(mp):
 
 
 @pytest.mark.gpu
-def test_range_sentinel_in_plain_forward(mp):
-    """The fp16-split path may not leave its range silently (ADVICE r02 / VERDICT r02 item 1f).  (1) an input of |u| ~ 1000 through
-    plain forward(): the status word carries INPUT_RANGE (prepare kernel) and NODE_SATURATED (tile staging) once the work has
-    completed, and the NEXT forward warns (one host read, no sync inside forward).  (2) hidden activations beyond fp16 (|Swish| >
-    1023, made with a huge message_net_1 bias): NODE_SATURATED (the aggregate is NaN / out of range) or NONFINITE (the norm's
-    statistics).  (3) in-range data leaves the word at 0 (also asserted after every GPU test by conftest)."""
+def test_out_of_range_forward_returns_the_reference_result(mp):
+    """VERDICT r03 item 7 (the reference has no input-range contract, models_gnn.py:1315-1377): plain forward() on data outside
+    the fp16-split path's range must return the reference's answer, not a saturated one with a warning a call later.
+    (1) first forward of a model ('auto' policy: checked synchronously) on |u| ~ 1000: one MsmpRangeWarning, the forward is
+        evaluated again on the exact-fp32 kernels, the result matches the float64 oracle, the model stays exact, the sticky word is
+        cleared;  (2) a model that has been probed on in-range data meets out-of-range data later: the flag is seen at the NEXT
+        entry (no synchronisation), the model switches from that call on;  (3) range_policy = 'sync': every call is checked;
+    (4) hidden activations beyond fp16 (a huge message_net_1 bias): same switch;  (5) range_policy = 'warn' is round 3's
+        behaviour;  (6) in-range data never trips anything (also asserted after every GPU test by conftest)."""
+    import copy
     import warnings
+    from types import SimpleNamespace
     from msmp_pde_amd.synthetic import make_case
     torch.manual_seed(3)
     c = make_case('E2', 3, seed=9, device='cuda', dtype=torch.float64)
     steps = [50] * 3
     data, labels = c.creator.create_data(c.u_super, steps)
     graph = c.creator.create_graph(data, labels, c.x, c.variables, steps)
-    model = mp.MP_PDE_SolverLEMLinGated(c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=2).cuda().eval()
-    with torch.no_grad():
-        model(graph)
-    torch.cuda.synchronize()
-    assert mp.last_status() == 0                                     # (3)
-    x0 = graph.x
-    graph.x = x0 + 1000.0
-    with torch.no_grad():
-        model(graph)
-    torch.cuda.synchronize()
-    flags = mp.last_status()
-    assert flags & mp.MSMP_STATUS_INPUT_RANGE and flags & mp.MSMP_STATUS_NODE_SATURATED, flags           # (1)
-    graph.x = x0
-    with pytest.warns(mp.MsmpRangeWarning, match='split'):
-        with torch.no_grad():
-            model(graph)
-    with warnings.catch_warnings():                                  # ... once: the same flags do not warn again
+    kind = 'MP_PDE_SolverLEMLinGated'
+    mk = lambda: getattr(mp, kind)(c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=2).cuda().eval()
+
+    def oracle(model, g):
+        sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        gg = SimpleNamespace(**{k: v.detach().cpu().numpy() for k, v in g.__dict__.items() if torch.is_tensor(v)})
+        return O.solver_forward(kind, sd, gg, c.pde, TW, c.eqv, 2)
+
+    def close(out, ref, rel=2e-3):
+        err = np.abs(out.double().cpu().numpy() - ref).max()
+        assert np.isfinite(out.cpu().numpy()).all() and err < rel * np.abs(ref).max(), (err, np.abs(ref).max())
+        return err
+
+    far = copy.copy(graph)
+    far.x = graph.x + 1000.0
+    # (6) + probe on in-range data
+    model = mk()
+    with warnings.catch_warnings():
         warnings.simplefilter('error', mp.MsmpRangeWarning)
         with torch.no_grad():
-            model(graph)
+            out = model(graph)
+    torch.cuda.synchronize()
+    assert mp.last_status() == 0 and model._range_probed and not model._range_exact
+    close(out, oracle(model, graph))
+    # (1)
+    m1 = mk()
+    with pytest.warns(mp.MsmpRangeWarning, match='evaluated again'):
+        with torch.no_grad():
+            out = m1(far)
+    torch.cuda.synchronize()
+    err = close(out, oracle(m1, far))
+    print(f'|u| ~ 1000 through plain forward(): max|hip - oracle| = {err:.3e}')
+    assert m1._range_exact and mp.last_status() == 0
+    with warnings.catch_warnings():                                  # ... and stays exact without warning again
+        warnings.simplefilter('error', mp.MsmpRangeWarning)
+        with torch.no_grad():
+            close(m1(far), oracle(m1, far))
+    torch.cuda.synchronize()
+    assert mp.last_status() == 0                                     # the exact kernels have no range to leave
+    # (2) the already-probed model: the call that leaves the range returns before anyone looks ...
+    with torch.no_grad():
+        model(far)
+    torch.cuda.synchronize()
+    assert mp.last_status() & mp.MSMP_STATUS_INPUT_RANGE and not model._range_exact
+    with pytest.warns(mp.MsmpRangeWarning, match='EARLIER'):         # ... the next entry sees the flag and switches
+        with torch.no_grad():
+            out = model(far)
+    torch.cuda.synchronize()
+    close(out, oracle(model, far))
+    assert model._range_exact and mp.last_status() == 0
+    # (3)
+    m3 = mk()
+    m3.range_policy = 'sync'
+    with torch.no_grad():
+        m3(graph)
+        with pytest.warns(mp.MsmpRangeWarning, match='evaluated again'):
+            out = m3(far)
+    close(out, oracle(m3, far))
+    assert mp.last_status() == 0
+    # (4)
+    m4 = mk()
+    with torch.no_grad():
+        m4.gnn_layers[0].message_net_1[0].bias.fill_(5000.0)
+        mp.invalidate_packed_weights()
+        with pytest.warns(mp.MsmpRangeWarning, match='evaluated again'):
+            out = m4(graph)
+    torch.cuda.synchronize()
+    assert m4._range_exact and bool(torch.isfinite(out).all()) and mp.last_status() == 0
+    close(out, oracle(m4, graph), rel=5e-2)       # pre-activations of 5000 +- 1 in front of an InstanceNorm: float32 itself is at ~1e-2 here
+    # (5)
+    m5 = mk()
+    m5.range_policy = 'warn'
+    with torch.no_grad():
+        m5(far)
+    torch.cuda.synchronize()
+    flags = mp.last_status()
+    assert flags & mp.MSMP_STATUS_INPUT_RANGE and not m5._range_exact
+    with pytest.warns(mp.MsmpRangeWarning, match='split'):
+        with torch.no_grad():
+            m5(graph)
     torch.cuda.synchronize()
     assert mp.last_status(reset=True) == flags                       # sticky until reset; in-range work added nothing
-    with torch.no_grad():                                            # (2)
-        model.gnn_layers[0].message_net_1[0].bias.fill_(5000.0)
-        mp.invalidate_packed_weights()
-        out = model(graph)
-    torch.cuda.synchronize()
-    flags = mp.last_status(reset=True)
-    assert flags & (mp.MSMP_STATUS_NODE_SATURATED | mp.MSMP_STATUS_NONFINITE), (flags, bool(torch.isfinite(out).all()))
-    assert not flags & mp.MSMP_STATUS_INPUT_RANGE
 
 
 @pytest.mark.gpu
