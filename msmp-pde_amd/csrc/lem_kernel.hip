@@ -1123,7 +1123,11 @@ __device__ __forceinline__ void lem_ws1_phase(const half8 (&w0)[4][2][2], const 
         LemPairTmp tmp;
         half8 nh0 = h0, nl0 = l0, nh1 = h1, nl1 = l1;
         __builtin_amdgcn_sched_barrier(0);
-        if (MSMP_LOLO >= 2) mfma_aw(o0, w0[kt][s][1], l0);
+        // The two accumulators ALTERNATE: a dependent MFMA that is not issued right behind its producer waits for the producer's
+        // write-back (~64 clocks after issue: the anti-phased kernel measured 2x for alternating accumulators with nothing between
+        // them; with one vector piece between the MFMAs the dependent one is two MFMAs and two pieces behind -- nothing waits, and
+        // each chain still accumulates in its own order (w_lo h, w_hi l, w_hi h per K group): the same bits).
+        if (MSMP_LOLO >= 2) { mfma_aw(o0, w0[kt][s][1], l0); mfma_aw(o1, w1[kt][s][1], l1); }
         mfma_aw(o0, w0[kt][s][1], h0);
         if (g < 7) {                                // next group's fragments: requested behind this group's first MFMA
             const int f = (g + 1) * 2;
@@ -1136,17 +1140,16 @@ __device__ __forceinline__ void lem_ws1_phase(const half8 (&w0)[4][2][2], const 
         }
         if (DO_V) lem_ws1_piece<0>(i0, i1, r, c0, c1, idt, st, tmp, phi, plo, j);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_aw(o0, w0[kt][s][0], l0);
+        mfma_aw(o1, w1[kt][s][1], h1);
         if (DO_V) lem_ws1_piece<1>(i0, i1, r, c0, c1, idt, st, tmp, phi, plo, j);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_aw(o0, w0[kt][s][0], h0);
+        mfma_aw(o0, w0[kt][s][0], l0);
         if (DO_V) lem_ws1_piece<2>(i0, i1, r, c0, c1, idt, st, tmp, phi, plo, j);
         __builtin_amdgcn_sched_barrier(0);
-        if (MSMP_LOLO >= 2) mfma_aw(o1, w1[kt][s][1], l1);
-        mfma_aw(o1, w1[kt][s][1], h1);
+        mfma_aw(o1, w1[kt][s][0], l1);
         if (DO_V) lem_ws1_piece<3>(i0, i1, r, c0, c1, idt, st, tmp, phi, plo, j);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_aw(o1, w1[kt][s][0], l1);
+        mfma_aw(o0, w0[kt][s][0], h0);
         if (DO_V) lem_ws1_piece<4>(i0, i1, r, c0, c1, idt, st, tmp, phi, plo, j);
         __builtin_amdgcn_sched_barrier(0);
         mfma_aw(o1, w1[kt][s][0], h1);
@@ -1263,26 +1266,36 @@ __global__ __launch_bounds__(256, 1) void lem_encoder_ws1_kernel(LemWsArgs a) {
     lem_ws_slots<P>(xn0, hh, bx0);
     lem_ws_slots<P>(xn1, hh, bx1);
 
+    const int role = 0;
+    (void)role;
+    LPROF_DECL
     for (int t = 0; t < T; ++t) {
         const int tn = t + 1 < T ? t + 1 : t;
         // phase 0: M_A(0,t) || V_B(1,t-1)  (nothing to update before the first step)
         if (t == 0) lem_ws1_phase<true, false, M>(w[0], w[1], wxw, wxw + M * 64, bx0, fy0, fy0, a0, a1, d0, d1, c0, c1b, idt, sy[1], py1);
         else lem_ws1_phase<true, true, M>(w[0], w[1], wxw, wxw + M * 64, bx0, fy0, fy0, a0, a1, d0, d1, c0, c1b, idt, sy[1], py1);
-        __syncthreads();
+        LPROF(lp_m);
+        LEM_SYNC();
         // phase 1: M_A(1,t) || V_A(0,t)
         lem_ws1_phase<true, true, M>(w[0], w[1], wxw, wxw + M * 64, bx1, fy1, fy1, b0, b1, a0, a1, c0, c1a, idt, sz[0], pz0);
-        __syncthreads();
+        LPROF(lp_m);
+        LEM_SYNC();
         // phase 2: M_B(0,t) || V_A(1,t); x_0(t+1) requested, its fragments formed behind the phase (the last use of x_0(t) is this phase's)
         fetch0(tn);
         lem_ws1_phase<false, true, M>(w[2], w[3], wxw + 2 * M * 64, wxw + 3 * M * 64, bx0, fy0, fz0, c0a, c1acc, b0, b1, c0, c1a, idt, sz[1], pz1);
+        LPROF(lp_m);
         lem_ws_slots<P>(xn0, hh, bx0);
-        __syncthreads();
+        LPROF(lp_v);
+        LEM_SYNC();
         // phase 3: M_B(1,t) || V_B(0,t); x_1(t+1) likewise
         fetch1(tn);
         lem_ws1_phase<false, true, M>(w[2], w[3], wxw + 2 * M * 64, wxw + 3 * M * 64, bx1, fy1, fz1, d0, d1, c0a, c1acc, c0, c1b, idt, sy[0], py0);
+        LPROF(lp_m);
         lem_ws_slots<P>(xn1, hh, bx1);
-        __syncthreads();
+        LPROF(lp_v);
+        LEM_SYNC();
     }
+    LPROF_FLUSH
     {   // V_B(1, T-1): the last update of tile 1
         half8 phi, plo;
 #pragma unroll

@@ -55,7 +55,7 @@ def deep_state_dict(d, shapes=None):
 DEEP_CASES = [('MP_PDE_Solver', 'E2'), ('MP_PDE_SolverGated', 'E2'), ('MP_PDE_SolverGated', 'WE3'),
               ('MP_PDE_Solver2DGated', 'MSWG3'), ('MP_PDE_Solver2DGated', 'RPU')]
 
-_PARITY_LOG = os.environ.get('MSMP_PARITY_LOG', os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out', 'parity_r03.json'))
+_PARITY_LOG = os.environ.get('MSMP_PARITY_LOG', os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out', 'parity_r04.json'))
 
 
 def record_parity(test, case, **numbers):

@@ -8,8 +8,9 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import msmp_oracle as O
 from oracle import msmp_oracle_torch as OT
-from helpers import synthetic_case
+from helpers import synthetic_case, fp32_floors, assert_parity, record_parity, err_stats
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -647,3 +648,63 @@ def test_captured_training_step_follows_the_eager_trajectory(mp, name, exp):
     for a, b, b2 in zip(we, wc, wc2):
         assert torch.equal(a, b) and torch.equal(b, b2)
     assert all(torch.equal(a, b) for a, b in zip(lc, lc2))
+
+
+@pytest.mark.parametrize('exp', ['E2', 'WE3'])
+def test_parity_at_a_trained_operating_point(mp, exp):
+    """every full-depth parity number so far is at UNTRAINED default-init weights, where the InstanceNorm stack is
+    ill-conditioned and float32 itself misses north_star's 1e-5 on the MSMP-PDE classes.  Here the headline class
+    (MP_PDE_SolverLEMLinGated, 6 gated pairs) is trained for 300 captured optimisation steps (train.CapturedTrainStep, the
+    reference's batch of 16, experiments/train_helper.py:125-141; AdamW, lr 1e-4 as experiments/train.py) on the synthetic E2 / WE3
+    trajectories of a fixed seed, and the HIP forward on the trained weights -- one forward on held-out samples and one rollout step
+    on its own prediction (models_gnn.py:1365-1368, common/utils.py:431-471) -- is compared with the float64 oracle and with the
+    float32 floor.  The bar asserted is the suite's (max(1e-5, 2 x floor)); whether the plain 1e-5 holds is RECORDED
+    (profiles/parity_r04.json: 'meets_plain_1e-5'), not assumed."""
+    from types import SimpleNamespace
+    from msmp_pde_amd import train as T
+    from msmp_pde_amd.synthetic import make_case
+    kind = 'MP_PDE_SolverLEMLinGated'
+    bsz = 16
+    c = make_case(exp, bsz, seed=9, device='cuda', dtype=torch.float32)
+    gs = []
+    for i in range(8):
+        steps = [40 + 7 * i + (j % 5) for j in range(bsz)]
+        data, labels = c.creator.create_data(c.u_super, steps)
+        gs.append(c.creator.create_graph(data, labels, c.x, c.variables, steps))
+    torch.manual_seed(11)
+    model = getattr(mp, kind)(c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=6).cuda()
+    opt = mp.optim.AdamW(model.parameters(), lr=1e-4, capturable=True)
+    step = T.CapturedTrainStep(model, opt, gs[0], warmup=3)
+    losses = [float(step(gs[i % len(gs)])) for i in range(300)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and np.mean(losses[-16:]) < 0.8 * np.mean(losses[:16]), (losses[:4], losses[-4:])
+    model.eval()
+    # held-out samples of the same distribution, the reference's evaluation step
+    ce = make_case(exp, 8, seed=77, device='cuda', dtype=torch.float64)
+    st = [75] * 8
+    data, labels = ce.creator.create_data(ce.u_super, st)
+    graph = ce.creator.create_graph(data, labels, ce.x, ce.variables, st)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    to_np = lambda g: SimpleNamespace(**{k: v.detach().cpu().numpy() for k, v in g.__dict__.items() if torch.is_tensor(v)})
+    results = {}
+    with torch.no_grad():
+        pred = model(graph)
+    for tag in ('forward', 'rollout_step'):
+        if tag == 'rollout_step':                   # the state update on the HIP prediction, then the next forward: the same input for both sides
+            st = [100] * 8
+            _, lab = ce.creator.create_data(ce.u_super, st)
+            graph = ce.creator.create_next_graph(graph, pred, lab, st)
+            with torch.no_grad():
+                pred = model(graph)
+        g = to_np(graph)
+        ref = O.solver_forward(kind, sd, g, ce.pde, TW, ce.eqv, 6)
+        floor = fp32_floors(kind, sd, g, ce.pde, TW, ce.eqv, 6)
+        out = pred.double().cpu().numpy()
+        err, rms = err_stats(out, ref)
+        results[tag] = (err, rms)
+        assert_parity('parity_at_a_trained_operating_point', f'{kind}/{exp}/trained300/{tag}', out, ref, floor)
+        record_parity('trained_operating_point', f'{kind}/{exp}/{tag}', max_abs=err, rms=rms, out_scale=float(np.abs(ref).max()),
+                      fp32_floor_max=max(err_stats(v, ref)[0] for v in floor.values()), meets_plain_1e_5=bool(err <= 1e-5),
+                      loss_first16=float(np.mean(losses[:16])), loss_last16=float(np.mean(losses[-16:])), optimisation_steps=300)
+    print(f'{exp} trained 300 steps (loss {np.mean(losses[:16]):.3f} -> {np.mean(losses[-16:]):.3f}): '
+          + ', '.join(f'{k}: max {v[0]:.2e} rms {v[1]:.2e}' for k, v in results.items()))
