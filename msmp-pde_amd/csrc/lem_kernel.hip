@@ -1048,7 +1048,11 @@ __global__ __launch_bounds__(512) void lem_encoder_ws3_kernel(LemWsArgs a) {
 // live there for the whole kernel, the 256 architectural registers hold states, accumulators and the vector work.  (Left to the
 // register allocator the weights end up in AGPRs as SPILL slots: four v_accvgpr_read per fragment in front of every MFMA.)
 // Inline asm is invisible to the hazard recogniser: B comes from LDS reads (waited for by the compiler), acc is read by vector
-// instructions only a whole phase (and a barrier) later, and consecutive MFMAs on one accumulator issue back to back.
+// instructions only a whole phase (and a barrier) later, and a B-fragment register is next written by an LDS read issued at least one
+// K group (six MFMAs) after the MFMA that read it.  (A queued dependent MFMA reads its A / B operands when it STARTS, tens of clocks
+// after it issued: round 4 measured run-to-run differences of 1e-1 in the node tail when an inline-asm split overwrote B registers two
+// instructions behind the MFMAs that read them.  This edition is opt-in -- msmp_tune("lem", 5) -- and checked bit for bit against the
+// default edition in tests/test_gpu_kernels.py; the default edition's MFMAs are compiler builtins.)
 __device__ __forceinline__ void mfma_aw(f32x16& acc, const half8& w_agpr, const half8& b) {
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_agpr), "v"(b));
 }

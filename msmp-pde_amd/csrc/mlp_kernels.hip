@@ -1038,6 +1038,9 @@ __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, cons
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const f32x4 v0 = pf[2 * s], v1 = pf[2 * s + 1];
+                // (the two-instruction v_fma_mix split of the tile kernel's stage is NOT used here: it is inline asm, invisible to the
+                // hazard recogniser, and in this loop it would overwrite B-fragment registers that the previous chunk's MFMAs are
+                // still reading -- measured in round 4: run-to-run differences of 1e-1 in the layer output)
                 const float v[8] = {tail_node_scaled(v0[0]), tail_node_scaled(v0[1]), tail_node_scaled(v0[2]), tail_node_scaled(v0[3]),
                                     tail_node_scaled(v1[0]), tail_node_scaled(v1[1]), tail_node_scaled(v1[2]), tail_node_scaled(v1[3])};
                 split8(v, bhi[0][s], blo[0][s]);

@@ -61,13 +61,18 @@ class AdamW(torch.optim.Optimizer):
                 dev = self._device_state(group, live)
                 if not torch.cuda.is_current_stream_capturing():
                     self.sync_lr()
-                for _, plan in self._plans(group, live):
-                    n = len(plan['params'])
-                    grads = (ctypes.c_void_p * n)(*[p.grad.data_ptr() for p in plan['params']])
-                    check(L.msmp_adamw_capturable_f32(n, plan['p'], grads, plan['m'], plan['v'], plan['numel'], dev['lr'].data_ptr(), float(b1), float(b2),
-                                                      float(group['eps']), float(group['weight_decay']), dev['step'].data_ptr(), current_stream()),
-                          'msmp_adamw_capturable_f32')
-                    break           # one plan: the group shares its step count (checked in _device_state)
+                plans = self._plans(group, live)
+                if len(plans) != 1:
+                    # the device-side count is ONE word per group: parameters with another host-side step (state loaded at step N plus
+                    # a parameter that gets its first gradient now) would be skipped or mis-corrected
+                    raise RuntimeError('msmp_pde_amd.optim.AdamW(capturable=True): the live parameters of a group carry '
+                                       f'{len(plans)} different step counts; a capturable group shares one')
+                plan = plans[0][1]
+                n = len(plan['params'])
+                grads = (ctypes.c_void_p * n)(*[p.grad.data_ptr() for p in plan['params']])
+                check(L.msmp_adamw_capturable_f32(n, plan['p'], grads, plan['m'], plan['v'], plan['numel'], dev['lr'].data_ptr(), float(b1), float(b2),
+                                                  float(group['eps']), float(group['weight_decay']), dev['step'].data_ptr(), current_stream()),
+                      'msmp_adamw_capturable_f32')
                 continue
             # One launch per step count: parameters that received their first gradient later than their group peers (torch handles
             # that) carry their own count, like everything else in torch's per-parameter state layout.

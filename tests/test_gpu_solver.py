@@ -633,6 +633,34 @@ def test_sub_batches_on_streams_match_the_whole_batch(mp, name, exp, parts):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name,exp', [('MSMP-PDE', 'E2'), ('MP-PDE', 'E2'), ('SaveMSMP-PDE', 'E2')])
+def test_sub_batches_with_cold_caches_and_stateful_encoders(mp, name, exp):
+    """the model's lazily packed operands (layer blobs, encoder blob, LEM pack, cumsum(dt)) are created by
+    whichever stream gets there first; with sub_batches > 1 the OTHER streams consumed them with no dependency on the pack kernels.
+    (1) the multi-stream forward is the FIRST forward after invalidate_packed_weights() (every cache cold: Solver.warm_caches packs
+    them on the caller's stream, which every side stream waits for), repeated, against the single-stream result;  (2) a stateful
+    encoder (LEMS carries (y, z) from call to call: sub-batch 1 would start from sub-batch 0's states) takes the single-stream path
+    whatever sub_batches says, and its rollout equals the sub_batches = 1 rollout."""
+    torch.manual_seed(2)
+    case = synthetic_case(mp, exp, bsz=6, seed=4)
+    mk = lambda: mp.MODEL_NAMES[name](case.pde, time_window=TW, eq_variables=case.eqv, hidden_layer=2).cuda().eval()
+    torch.manual_seed(5)
+    m1 = mk()
+    torch.manual_seed(5)
+    m2 = mk()
+    m2.sub_batches = 3
+    data = case.graph.to('cuda')
+    with torch.no_grad():
+        for it in range(4):
+            ref = m1(data)
+            mp.invalidate_packed_weights()           # every packed operand of m2 is stale: the next forward re-packs all of them
+            torch.cuda.synchronize()
+            out = m2(data)
+            assert torch.equal(out, ref), (name, it)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 def test_forwards_on_two_streams_do_not_share_scratch(mp):
     """Two batches evaluated concurrently on two streams of one device (what an overlapped rollout of sub-batches does) give the bits of
     the one-after-the-other evaluation: the layers' scratch workspace is per (device, stream)."""
