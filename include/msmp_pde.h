@@ -293,6 +293,30 @@ int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const fl
                       float eps, float* h_out, void* workspace, size_t workspace_bytes,
                       msmp_stream_t stream);
 
+/* The LAST layer (pair) of a 1-D solver with the decoder as the node tail's epilogue ("decoder fusion into
+ * the last layer's epilogue"; experiments/models_gnn.py:1365-1375: the loop's last iteration, then output_mlp and the Euler update):
+ * h_out is still written (the rows are read back from L2 by the workgroup that wrote them, not from HBM), dec->out receives
+ * out = u[:, -1] + cumsum(dt) * Conv1d(8,1,k2)(Swish(Conv1d(1,8,k1,stride s1)(h_out))) (dec->u == NULL: the decoder output alone),
+ * bit-identical to msmp_mp_layer_f32 followed by msmp_decoder_f32.  Returns MSMP_ERR_UNSUPPORTED where the fused tail does not
+ * apply (time_window != 25, graphs of more than 128 nodes, msmp_tune "split" / "tail" off): call the two entry points then. */
+typedef struct {
+    const float* w1;             /* output_mlp[0].weight [8,1,k1] */
+    const float* b1;             /* output_mlp[0].bias   [8]      */
+    const float* w2;             /* output_mlp[2].weight [1,8,k2] */
+    const float* b2;             /* output_mlp[2].bias   [1]      */
+    const float* u;              /* [N, time_window] or NULL      */
+    float dt;
+    int32_t time_window;
+    float* out;                  /* [N, time_window]              */
+} msmp_decoder_t;
+int msmp_mp_layer_decode_f32(const float* h, const float* u, const float* pos, const float* vars,
+                             const float* feat, const int32_t* rowptr, const int32_t* col, const int32_t* tgt,
+                             const msmp_tiles_t* tiles, const int32_t* graph_ptr, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                             int max_in_degree, int max_graph_nodes, int tw, int nv, const float* packed_main,
+                             const float* packed_gate, int mode,
+                             float eps, float* h_out, const msmp_decoder_t* dec, void* workspace, size_t workspace_bytes,
+                             msmp_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * LEM node encoder (replaces the absent `lem_cuda` extension)
  * ------------------------------------------------------------------------------------------- */

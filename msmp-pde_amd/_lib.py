@@ -13,6 +13,12 @@ class MsmpTiles(ctypes.Structure):
                 ('tile_halo', c_void_p), ('edge_slot', c_void_p), ('listed', ctypes.c_int32), ('period_tiles', ctypes.c_int32), ('period_nodes', ctypes.c_int32)]
 
 
+class MsmpDecoder(ctypes.Structure):
+    """msmp_decoder_t (include/msmp_pde.h): the 1-D decoder as the epilogue of the last layer's node tail."""
+    _fields_ = [('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('u', c_void_p), ('dt', ctypes.c_float),
+                ('time_window', ctypes.c_int32), ('out', c_void_p)]
+
+
 MSMP_TILE_NCAP = 32
 MSMP_TILE_EDGES = 128
 MSMP_TILE_GROUP_EDGES = 32      # edge lanes of one wave group of a tile
@@ -56,6 +62,8 @@ SIGNATURES = {
     'msmp_mp_layer_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int, c_int]),
     'msmp_mp_layer_f32': (c_int, [c_void_p] * 8 + [ctypes.POINTER(MsmpTiles), c_void_p] + [c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                                    c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'msmp_mp_layer_decode_f32': (c_int, [c_void_p] * 8 + [ctypes.POINTER(MsmpTiles), c_void_p] + [c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                                          c_float, c_void_p, ctypes.POINTER(MsmpDecoder), c_void_p, c_size_t, c_void_p]),
     'msmp_packed_lem_floats': (c_int64, []),
     'msmp_pack_lem_f32': (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p]),
     'msmp_lem_input_stride': (c_int, [c_int]),

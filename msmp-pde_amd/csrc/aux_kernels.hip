@@ -525,12 +525,43 @@ extern "C" size_t msmp_mp_layer_workspace_bytes(int64_t n_nodes, int64_t n_edges
     return msg + nod * 6 + 256;
 }
 
+static int mp_layer_impl(const float* h, const float* u, const float* pos, const float* vars, const float* feat,
+                         const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const msmp_tiles_t* tiles,
+                         const int32_t* graph_ptr,
+                         int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int max_in_degree, int max_graph_nodes,
+                         int tw, int nv, const float* packed_main, const float* packed_gate, int mode, float eps, float* h_out,
+                         const msmp_decoder_t* dec, void* workspace, size_t workspace_bytes, msmp_stream_t stream);
+
 extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* pos, const float* vars, const float* feat,
                                  const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const msmp_tiles_t* tiles,
                                  const int32_t* graph_ptr,
                                  int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int max_in_degree, int max_graph_nodes,
                                  int tw, int nv, const float* packed_main, const float* packed_gate, int mode, float eps, float* h_out,
                                  void* workspace, size_t workspace_bytes, msmp_stream_t stream) {
+    return mp_layer_impl(h, u, pos, vars, feat, rowptr, col, tgt, tiles, graph_ptr, n_nodes, n_edges, n_graphs, max_in_degree, max_graph_nodes, tw, nv,
+                         packed_main, packed_gate, mode, eps, h_out, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int msmp_mp_layer_decode_f32(const float* h, const float* u, const float* pos, const float* vars, const float* feat,
+                                        const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const msmp_tiles_t* tiles,
+                                        const int32_t* graph_ptr,
+                                        int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int max_in_degree, int max_graph_nodes,
+                                        int tw, int nv, const float* packed_main, const float* packed_gate, int mode, float eps, float* h_out,
+                                        const msmp_decoder_t* dec, void* workspace, size_t workspace_bytes, msmp_stream_t stream) {
+    MSMP_REQUIRE(dec, MSMP_ERR_ARG, "msmp_mp_layer_decode_f32: null decoder description");
+    MSMP_REQUIRE(dec->time_window == 25 && msmp_tune_get("split") && msmp_tune_get("tail") && max_graph_nodes > 0 && max_graph_nodes <= 128,
+                 MSMP_ERR_UNSUPPORTED, "msmp_mp_layer_decode_f32: the fused tail does not apply (time_window %d, max_graph_nodes %d)", dec->time_window,
+                 max_graph_nodes);
+    return mp_layer_impl(h, u, pos, vars, feat, rowptr, col, tgt, tiles, graph_ptr, n_nodes, n_edges, n_graphs, max_in_degree, max_graph_nodes, tw, nv,
+                         packed_main, packed_gate, mode, eps, h_out, dec, workspace, workspace_bytes, stream);
+}
+
+static int mp_layer_impl(const float* h, const float* u, const float* pos, const float* vars, const float* feat,
+                         const int32_t* rowptr, const int32_t* col, const int32_t* tgt, const msmp_tiles_t* tiles,
+                         const int32_t* graph_ptr,
+                         int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int max_in_degree, int max_graph_nodes,
+                         int tw, int nv, const float* packed_main, const float* packed_gate, int mode, float eps, float* h_out,
+                         const msmp_decoder_t* dec, void* workspace, size_t workspace_bytes, msmp_stream_t stream) {
     MSMP_REQUIRE(h && u && pos && vars && rowptr && col && tgt && graph_ptr && packed_main && h_out && workspace,
                  MSMP_ERR_ARG, "msmp_mp_layer_f32: null pointer");
     MSMP_REQUIRE(h_out != h, MSMP_ERR_ARG, "msmp_mp_layer_f32: h_out may not alias h");
@@ -592,9 +623,10 @@ extern "C" int msmp_mp_layer_f32(const float* h, const float* u, const float* po
             if (gated && (rc = aggregate(packed_gate, pre_gate))) return rc;       // pre_gate doubles as the gate head's aggregate
             if ((rc = aggregate(packed_main, agg))) return rc;
         } else if (rc) return rc;
-        return msmp_node_tail_f32(h, agg, gated ? pre_gate : nullptr, vars, graph_ptr, n_nodes, n_graphs, max_graph_nodes, nv,
-                                  packed_main, packed_gate, mode, eps, h_out, stream);
+        return msmp_node_tail_impl(h, agg, gated ? pre_gate : nullptr, vars, graph_ptr, n_nodes, n_graphs, max_graph_nodes, nv,
+                                   packed_main, packed_gate, mode, eps, h_out, dec, stream);
     }
+    MSMP_REQUIRE(!dec, MSMP_ERR_UNSUPPORTED, "msmp_mp_layer_decode_f32: the fused tail does not apply");
     if (gated) {
         if ((rc = aggregate(packed_gate, agg))) return rc;
         if ((rc = msmp_node_update_f32(h, agg, vars, n_nodes, nv, packed_gate, MSMP_LAYER_LIN, pre_gate, stream))) return rc;

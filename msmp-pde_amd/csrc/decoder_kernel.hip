@@ -7,6 +7,7 @@
 // constants: the compiler keeps them in SGPRs (scalar loads).  ~7.7 kFMA per node: VALU work, ~3 GFLOP per
 // E2-2048 batch; HBM traffic N*(512 + 4 + 100) bytes = 126 MB.
 #include "msmp_common.h"
+#include "decoder_body.h"
 
 namespace msmp {
 
@@ -88,92 +89,15 @@ __global__ __launch_bounds__(256) void decoder_kernel(DecArgs a) {
 // workgroups per CU.  The taps of every sum are added in the order of decoder_kernel: the same bits.
 // ----------------------------------------------------------------------------------------------
 template <int TW, int K1, int S1, int K2>
-struct DecSplit {
-    static constexpr int L1 = (H - K1) / S1 + 1;
-    static constexpr int PP = (L1 + 7) / 8;                          // intermediate positions per lane
-    static constexpr int XW = (PP - 1) * S1 + K1;                    // row values a lane needs
-    static constexpr int OPL = TW > 32 ? 8 : 4;                      // consecutive outputs per lane (multiple of 4: aligned 16-byte LDS reads)
-    static constexpr int MW = OPL + K2 - 1;                          // intermediate values per channel a lane needs for them
-    static constexpr int MW4 = (MW + 3) / 4;
-    static constexpr int LP = ((7 * OPL + 4 * MW4 > L1 ? 7 * OPL + 4 * MW4 : L1) + 3) / 4 * 4 + 4;      // padded row of the LDS table
-    static constexpr int NODES = 8 * LP * 4 * 32 <= 49152 ? 32 : 16;  // nodes per workgroup (LDS <= 48 KB)
-    static_assert(L1 - K2 + 1 == TW && 8 * OPL >= TW, "decoder geometry");
-};
-
-template <int TW, int K1, int S1, int K2>
 __global__ __launch_bounds__(256) void decoder_split_kernel(DecArgs a) {
     using G = DecSplit<TW, K1, S1, K2>;
-    constexpr int L1 = G::L1, PP = G::PP, XW = G::XW, OPL = G::OPL, MW4 = G::MW4, LP = G::LP, NODES = G::NODES;
+    constexpr int LP = G::LP, NODES = G::NODES;
     __shared__ __attribute__((aligned(16))) float mid[NODES * 8 * LP];
     const int q = threadIdx.x & 7, nl = threadIdx.x >> 3;
     const long n = (long)blockIdx.x * NODES + nl;
     const long nc = n < a.n_nodes ? n : a.n_nodes - 1;
-    // ---- the lane's window of the row: positions p0 .. p0 + PP - 1 read x[p0 S1 .. p0 S1 + XW) (clamped inside the row) ----------
-    const int p0 = q * PP;
-    float x[XW];
-    {
-        const float* row = a.h + (size_t)nc * H;
-        const int x0 = p0 * S1;
-#pragma unroll
-        for (int i = 0; i < XW; ++i) x[i] = row[x0 + i < H ? x0 + i : H - 1];
-    }
-    float* mrow = mid + (size_t)nl * 8 * LP;
-#pragma unroll 1
-    for (int c = 0; c < 8; ++c) {
-        float w1c[K1];
-#pragma unroll
-        for (int j = 0; j < K1; ++j) w1c[j] = a.w1[c * K1 + j];
-        const float bc = a.b1[c];
-        float s[PP];
-#pragma unroll
-        for (int pp = 0; pp < PP; ++pp) s[pp] = bc;
-#pragma unroll
-        for (int j = 0; j < K1; ++j)
-#pragma unroll
-            for (int pp = 0; pp < PP; ++pp) s[pp] = fmaf(w1c[j], x[pp * S1 + j], s[pp]);
-#pragma unroll
-        for (int pp = 0; pp < PP; ++pp)
-            if (p0 + pp < L1) mrow[c * LP + p0 + pp] = swishf(s[pp]);
-    }
-    __syncthreads();
-    // ---- outputs t0 .. t0 + OPL - 1 of this lane -------------------------------------------------------------------------
-    const int t0 = q * OPL;
-    float o[OPL];
-    const float bias2 = a.b2[0];
-#pragma unroll
-    for (int i = 0; i < OPL; ++i) o[i] = bias2;
-#pragma unroll 1
-    for (int c = 0; c < 8; ++c) {
-        float w2c[K2];
-#pragma unroll
-        for (int j = 0; j < K2; ++j) w2c[j] = a.w2[c * K2 + j];
-        float m[4 * MW4];
-#pragma unroll
-        for (int i = 0; i < MW4; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(mrow + c * LP + t0 + 4 * i);
-            m[4 * i] = v[0]; m[4 * i + 1] = v[1]; m[4 * i + 2] = v[2]; m[4 * i + 3] = v[3];
-        }
-#pragma unroll
-        for (int j = 0; j < K2; ++j)
-#pragma unroll
-            for (int i = 0; i < OPL; ++i) o[i] = fmaf(w2c[j], m[i + j], o[i]);
-    }
-    if (n >= a.n_nodes || t0 >= TW) return;
-    float* op = a.out + (size_t)n * TW;
-    if (a.u == nullptr) {
-#pragma unroll
-        for (int i = 0; i < OPL; ++i)
-            if (t0 + i < TW) op[t0 + i] = o[i];
-        return;
-    }
-    const float ul = a.u[(size_t)n * TW + TW - 1];
-    float tcum = 0.f;
-    for (int t = 0; t < t0; ++t) tcum += a.dt;          // cumsum of a constant, float32 partial sums like torch.cumsum on the device
-#pragma unroll
-    for (int i = 0; i < OPL; ++i) {
-        tcum += a.dt;
-        if (t0 + i < TW) op[t0 + i] = ul + tcum * o[i];
-    }
+    const DecW w{a.w1, a.b1, a.w2, a.b2, a.u, a.dt, a.out};
+    decoder_split_node<TW, K1, S1, K2, false>(a.h + (size_t)nc * H, mid + (size_t)nl * 8 * LP, q, n < a.n_nodes, n, w, [] { __syncthreads(); });
 }
 
 // ----------------------------------------------------------------------------------------------

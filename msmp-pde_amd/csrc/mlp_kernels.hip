@@ -17,6 +17,7 @@
 // MFMA steps for both operands.  fp32 MFMA is an exact k-ordered fmaf chain (no reduced precision).
 #include <string.h>
 #include "mfma_tiles.h"
+#include "decoder_body.h"
 
 namespace msmp {
 
@@ -969,6 +970,7 @@ struct TailArgs {
     const float* scales[2];
     float* out;
     int* status;             // msmp_last_status word (or nullptr)
+    DecW dec;                // dec.w1 != nullptr: the 1-D decoder (time_window 25) runs as this launch's epilogue on the rows it wrote
 };
 
 // One update head, update_net_2 transposed: yT[T][r] = 2^s4 (W4 Swish(W3 [h ; agg ; vars] + b3) + b4)[channel 4 c + T]
@@ -1294,6 +1296,23 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
         }
     }
     PROF_MARK(4);
+    // Fused decoder (models_gnn.py:1371-1375 on the last pair's output): the graph's h' rows have just been stored by this
+    // workgroup; after the barrier (its release waits for the stores) they are read back past the L1 -- from the L2 they were written
+    // to, not from HBM -- by the position-split decoder, 32 nodes per pass, eight lanes per node, the per-node tables in the dead weight /
+    // row buffers (16 nodes each).  Same arithmetic as decoder_split_kernel: the same bits.
+    if (a.dec.w1) {
+        using G = DecSplit<25, 16, 3, 14>;
+        static_assert(16 * 8 * G::LP <= 2 * SPLIT_CHUNK_FLOATS && 16 * 8 * G::LP <= 2 * ROWBUF_FLOATS, "decoder tables must fit the dead buffers");
+        __syncthreads();
+        const int q = tid & 7, nl = tid >> 3;
+        float* mrow = (nl < 16 ? lds : rowbuf) + (nl & 15) * 8 * G::LP;
+        for (int p = 0; p < cnt; p += 32) {
+            const bool live = p + nl < cnt;
+            const long nn = live ? (long)n0 + p + nl : (long)n1 - 1;
+            decoder_split_node<25, 16, 3, 14, true>(a.out + (size_t)nn * H, mrow, q, live, nn, a.dec, [] { __syncthreads(); });
+            __syncthreads();
+        }
+    }
     PROF_FLUSH
 }
 
@@ -1355,6 +1374,7 @@ static int g_tile_arith = 1;  // ranged tiles: slot -> node arithmetically (tile
 static int g_tile_align = 0;  // host layer: cut node tiles at graph boundaries also where tile_nodes does not divide the graph size (bitwise graph-order / sharding equivariance on knn graphs, ~11-20 % more tiles there)
 static int g_tile = 2;       // node tiles (tile_kernels.hip): 2 fold the projections into the message kernel, 1 staged P / Q rows, 0 off
 static int g_bwd_gemm = 1;   // layer backward: row GEMMs on rows_gemm_kernel (bf16x3 MFMA, fused epilogues); 0: rocblas_sgemm + separate passes
+static int g_dec_fuse = 0;   // host layer: the 1-D decoder as the epilogue of the last layer's node tail (msmp_mp_layer_decode_f32); measured, not the default
 static int g_tail = 1;       // fused node tail (msmp_node_tail_f32) inside msmp_mp_layer_f32; msmp_tune("tail", 0) chains the pieces
 int msmp_tune_get(const char* key) {
     if (!strcmp(key, "split")) return g_split;
@@ -1365,6 +1385,7 @@ int msmp_tune_get(const char* key) {
     if (!strcmp(key, "tile_arith")) return g_tile_arith;
     if (!strcmp(key, "tile_align")) return g_tile_align;
     if (!strcmp(key, "decoder")) return g_decoder;
+    if (!strcmp(key, "dec_fuse")) return g_dec_fuse;
     if (!strcmp(key, "lem_tail")) return g_lem_tail;
     if (!strcmp(key, "lem_share")) return g_lem_share;
     return 0;
@@ -1380,6 +1401,7 @@ extern "C" int msmp_tune(const char* key, int value) {
     if (key && !strcmp(key, "tile_arith")) { g_tile_arith = value; return MSMP_OK; }
     if (key && !strcmp(key, "tile_align")) { g_tile_align = value; return MSMP_OK; }
     if (key && !strcmp(key, "decoder")) { g_decoder = value != 0; return MSMP_OK; }
+    if (key && !strcmp(key, "dec_fuse")) { g_dec_fuse = value != 0; return MSMP_OK; }
     if (key && !strcmp(key, "lem_tail")) { g_lem_tail = value != 0; return MSMP_OK; }
     if (key && !strcmp(key, "lem_share") && value >= 1 && value <= 16) { g_lem_share = value; return MSMP_OK; }
     if (key && !strcmp(key, "edge_nb")) { g_edge_nb = value; return MSMP_OK; }
@@ -1487,6 +1509,14 @@ extern "C" int msmp_node_tail_f32(const float* h, const float* agg_main, const f
                                   const int32_t* graph_ptr, int64_t n_nodes, int64_t n_graphs, int max_graph_nodes, int nv,
                                   const float* packed_main, const float* packed_gate, int mode, float eps, float* out,
                                   msmp_stream_t stream) {
+    return msmp_node_tail_impl(h, agg_main, agg_gate, vars, graph_ptr, n_nodes, n_graphs, max_graph_nodes, nv, packed_main, packed_gate, mode,
+                               eps, out, nullptr, stream);
+}
+
+// The same with the 1-D decoder as the launch's epilogue (library-internal: msmp_mp_layer_decode_f32)
+int msmp_node_tail_impl(const float* h, const float* agg_main, const float* agg_gate, const float* vars, const int32_t* graph_ptr,
+                        int64_t n_nodes, int64_t n_graphs, int max_graph_nodes, int nv, const float* packed_main, const float* packed_gate,
+                        int mode, float eps, float* out, const msmp_decoder_t* dec, msmp_stream_t stream) {
     MSMP_REQUIRE(h && agg_main && vars && graph_ptr && packed_main && out, MSMP_ERR_ARG, "msmp_node_tail_f32: null pointer");
     MSMP_REQUIRE((agg_gate != nullptr) == (packed_gate != nullptr), MSMP_ERR_ARG, "msmp_node_tail_f32: give both gate arguments or none");
     MSMP_REQUIRE(n_nodes > 0 && n_graphs > 0 && n_graphs < (1L << 31) && nv >= 1 && nv <= MSMP_MAX_VARS, MSMP_ERR_ARG,
@@ -1501,7 +1531,12 @@ extern "C" int msmp_node_tail_f32(const float* h, const float* agg_main, const f
     const float* pg = packed_gate ? packed_gate : packed_main;
     TailArgs a{h, {agg_main, agg_gate}, vars, graph_ptr, nv, mode, eps,
                {packed_main + L.b3, pg + L.b3}, {packed_main + L.b4, pg + L.b4}, {packed_main + L.w3vh, pg + L.w3vh},
-               {packed_main + L.w3s, pg + L.w3s}, {packed_main + L.w4t, pg + L.w4t}, {packed_main + L.scales, pg + L.scales}, out, split_status()};
+               {packed_main + L.w3s, pg + L.w3s}, {packed_main + L.w4t, pg + L.w4t}, {packed_main + L.scales, pg + L.scales}, out, split_status(), DecW{}};
+    if (dec) {
+        MSMP_REQUIRE(dec->w1 && dec->b1 && dec->w2 && dec->b2 && dec->out, MSMP_ERR_ARG, "msmp_mp_layer_decode_f32: null pointer in the decoder description");
+        MSMP_REQUIRE(dec->time_window == 25, MSMP_ERR_UNSUPPORTED, "msmp_mp_layer_decode_f32: the fused decoder is built for time_window 25 (got %d)", dec->time_window);
+        a.dec = DecW{dec->w1, dec->b1, dec->w2, dec->b2, dec->u, dec->dt, dec->out};
+    }
     timing_begin(MSMP_K_NODE_UPDATE, (hipStream_t)stream);
     if (packed_gate) hipLaunchKernelGGL(node_tail_split_kernel<true>, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(node_tail_split_kernel<false>, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, a);

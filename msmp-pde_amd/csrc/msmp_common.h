@@ -15,7 +15,10 @@ int msmp_edge_aggregate_tiled_pair(const float* h, const float* u, const float* 
                                    const msmp_tiles_t* tiles, int64_t n_nodes, int64_t n_edges, int tw, int nv, const float* packed_a,
                                    const float* packed_b, float* agg_a, float* agg_b, msmp_stream_t stream);   // tile_kernels.hip
 
-bool msmp_tiles_ok(const msmp_tiles_t* t, int64_t n_nodes);    // tile_kernels.hip: geometry of a caller-supplied tile descriptor
+bool msmp_tiles_ok(const msmp_tiles_t* t, int64_t n_nodes);
+int msmp_node_tail_impl(const float* h, const float* agg_main, const float* agg_gate, const float* vars, const int32_t* graph_ptr,
+                        int64_t n_nodes, int64_t n_graphs, int max_graph_nodes, int nv, const float* packed_main, const float* packed_gate,
+                        int mode, float eps, float* out, const msmp_decoder_t* dec, msmp_stream_t stream);       // mlp_kernels.hip    // tile_kernels.hip: geometry of a caller-supplied tile descriptor
 
 namespace msmp {
 

@@ -182,8 +182,10 @@ def node_features(u, pos_x, variables):
     return feat
 
 
-def _mp_layer_hip(h, u, pos_x, variables, gs, main, gate, eps, dense_message=None, feat=None):
-    """The HIP call proper (no autograd): msmp_mp_layer_f32."""
+def _mp_layer_hip(h, u, pos_x, variables, gs, main, gate, eps, dense_message=None, feat=None, decode=None):
+    """The HIP call proper (no autograd): msmp_mp_layer_f32.  decode = (conv1, conv2, u_or_None, dt, tw): the LAST layer of a 1-D solver
+    with the decoder as the node tail's epilogue (msmp_mp_layer_decode_f32): returns (h_out, prediction), or None where the fused
+    tail does not apply (the caller then takes the two entry points)."""
     L = lib()
     n = h.shape[0]
     out = torch.empty_like(h)
@@ -193,6 +195,20 @@ def _mp_layer_hip(h, u, pos_x, variables, gs, main, gate, eps, dense_message=Non
     ws_bytes = L.msmp_mp_layer_workspace_bytes(n, gs.n_edges, int(gated), gs.max_in_degree)
     ws = _Workspace.get(ws_bytes, h.device)
     tiles = gs.tiles()
+    if decode is not None:
+        c1, c2, u_last, dt, tw = decode
+        w = [p.detach().to(torch.float32).contiguous() for p in (c1.weight, c1.bias, c2.weight, c2.bias)]       # alive until the call returns (stream-ordered use follows)
+        pred = torch.empty(n, tw, dtype=torch.float32, device=h.device)
+        dec = _lib.MsmpDecoder(ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[3]), ptr(u_last), float(dt), int(tw), ptr(pred))
+        rc = L.msmp_mp_layer_decode_f32(ptr(h), ptr(u), ptr(pos_x), ptr(variables), ptr(feat), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt),
+                                        None if tiles is None else ctypes.byref(tiles[0]), ptr(gs.graph_ptr), n, gs.n_edges, gs.n_graphs, gs.max_in_degree,
+                                        gs.max_graph_nodes, main.time_window, main.n_variables, ptr(main.packed()), ptr(gate.packed()) if gated else None,
+                                        mode, eps, ptr(out), ctypes.byref(dec), ptr(ws), ws.numel(), current_stream())
+        if rc == _lib.MSMP_ERR_UNSUPPORTED:
+            return None
+        check(rc, 'msmp_mp_layer_decode_f32')
+        out._msmp_keep = w          # the kernels read the decoder weights after this returns
+        return out, pred
     check(L.msmp_mp_layer_f32(ptr(h), ptr(u), ptr(pos_x), ptr(variables), ptr(feat), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt),
                               None if tiles is None else ctypes.byref(tiles[0]), ptr(gs.graph_ptr), n, gs.n_edges, gs.n_graphs, gs.max_in_degree, gs.max_graph_nodes, main.time_window,
                               main.n_variables,
@@ -291,7 +307,7 @@ def _mp_layer_wide_autograd(h, u, pos_x, variables, gs, main, gate, eps):
     return (1.0 - tau) * h + tau * (out * torch.sigmoid(out))
 
 
-def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense_message=None, feat=None):
+def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense_message=None, feat=None, decode=None):
     """One message-passing layer (or one gated pair) on the device through msmp_mp_layer_f32.
     h [N,128], u [N,Tw], pos_x [N,1] or [N], variables [N,nv]: float32 CUDA tensors.
     dense_message: None -> module default (factorised message_net_1); True -> literal per-edge GEMM.
@@ -310,7 +326,9 @@ def mp_layer(h, u, pos_x, variables, structure, main, gate=None, eps=1e-5, dense
     assert n == gs.n_nodes and hd.shape[1] == HIDDEN and u.shape[1] == main.time_window
     assert variables.shape[1] == main.n_variables and pos_x.numel() == n
     if not need_grad:
-        return _mp_layer_hip(hd, u, pos_x, variables, gs, main, gate, eps, dense_message, feat)
+        return _mp_layer_hip(hd, u, pos_x, variables, gs, main, gate, eps, dense_message, feat, decode)
+    assert decode is None, 'the fused decoder epilogue is an inference path'
+
     from .autograd import MPLayerFunction
     params = list(main._params8()) + (list(gate._params8()) if gate is not None else [])
     hin = h if (h.dtype == torch.float32 and h.is_contiguous()) else h.to(torch.float32).contiguous()

@@ -500,11 +500,20 @@ class _SolverBase(nn.Module):
         dt = self._dt(u.device)
 
         h = self._encode(u, pos_x, pos_t, variables, dt)
+        # msmp_tune("dec_fuse", 1): the decoder as the epilogue of the LAST layer's node tail (1-D classes, time_window
+        # 25, inference): bit-identical, measured in round 4 -- off by default
+        fuse = (not self.TWO_D and not self.G2 and tw == 25 and self.hidden_features == 128 and not torch.is_grad_enabled()
+                and u.is_cuda and bool(lib().msmp_tune_query(b'dec_fuse')))
         for i in range(self.hidden_layer):
             if self.G2:
                 h = self._g2_pair(h, u, pos_x, variables, gs, i)
                 continue
             gate = self.gnn_layers_gate[i] if self.GATED else None
+            if fuse and i == self.hidden_layer - 1:
+                both = mp_layer(h, u, pos_x, variables, gs, self.gnn_layers[i], gate, feat=feat,
+                                decode=(self.output_mlp[0], self.output_mlp[2], None if self.RETURN_DIFF else u, float(self.pde.dt), tw))
+                if both is not None:
+                    return both[1].to(u_in.dtype)
             h = mp_layer(h, u, pos_x, variables, gs, self.gnn_layers[i], gate, feat=feat)
 
         return self._decode(h, u, u_in, dt, tw)

@@ -661,6 +661,37 @@ def test_sub_batches_with_cold_caches_and_stateful_encoders(mp, name, exp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name,exp,nx', [('MSMP-PDE', 'E2', 100), ('MP-PDE', 'E2', 100), ('Gated', 'WE3', 100), ('MSMP-PDE', 'E2', 40), ('MSSMP-PDE', 'E2', 100)])
+def test_decoder_fused_into_the_last_node_tail_is_bit_identical(mp, name, exp, nx):
+    """SURVEY 8f.4 / VERDICT r03 item 4: msmp_mp_layer_decode_f32 -- the last layer (pair) with the 1-D decoder as the node tail's
+    epilogue (the rows read back from L2 by the workgroup that wrote them) -- gives the prediction of msmp_mp_layer_f32 followed by
+    msmp_decoder_f32 bit for bit: plain and gated classes, three variable columns, graphs of 40 nodes (a partial second pass of the
+    32-node decoder rounds), and the decoder-output-only form of the MSSMP sub-solvers; over a few rollout steps."""
+    from msmp_pde_amd.synthetic import make_case
+    torch.manual_seed(6)
+    c = make_case(exp, 5, seed=4, device='cuda', nx=nx, dtype=torch.float64)
+    steps = [50] * 5
+    data, labels = c.creator.create_data(c.u_super, steps)
+    graph = c.creator.create_graph(data, labels, c.x, c.variables, steps)
+    model = mp.MODEL_NAMES[name](c.pde, time_window=TW, eq_variables=c.eqv, hidden_layer=2).cuda().eval()
+    L = mp.lib()
+    try:
+        with torch.no_grad():
+            for it in range(3):
+                L.msmp_tune(b'dec_fuse', 0)
+                ref = model(graph)
+                L.msmp_tune(b'dec_fuse', 1)
+                out = model(graph)
+                assert torch.equal(out, ref), (name, exp, it, (out - ref).abs().max().item())
+                same = [50 + TW * (it + 1)] * 5
+                _, lab = c.creator.create_data(c.u_super, same)
+                graph = c.creator.create_next_graph(graph, ref, lab, same)
+    finally:
+        L.msmp_tune(b'dec_fuse', 0)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 def test_forwards_on_two_streams_do_not_share_scratch(mp):
     """Two batches evaluated concurrently on two streams of one device (what an overlapped rollout of sub-batches does) give the bits of
     the one-after-the-other evaluation: the layers' scratch workspace is per (device, stream)."""
