@@ -701,17 +701,23 @@ def _tile_case(mp, exp, bsz, nx=100, neighbors=3, seed=3):
     return c, graph, structure_of(graph)
 
 
+@pytest.mark.parametrize('align', [0, 1])
 @pytest.mark.parametrize('exp,bsz,nx,neighbors', [('E2', 5, 100, 3), ('WE3', 4, 100, 3), ('RPU', 3, 100, 3), ('MSWG3', 2, 100, 8),
                                                   ('E2', 7, 40, 3), ('E2', 1, 100, 2)])
-def test_node_tiles_are_a_valid_cover(mp, exp, bsz, nx, neighbors):
+def test_node_tiles_are_a_valid_cover(mp, exp, bsz, nx, neighbors, align):
     """msmp_build_tiles: every tile lists its target nodes first, then each further source exactly once; the in-edges of wave
     group g (group_nodes consecutive targets) sit at lanes 32 g ..., in CSR order, at most 32 of them; every edge's slot pair
     points at its own target / source; lists stay within MSMP_TILE_NCAP (checked against a numpy rebuild)."""
     from msmp_pde_amd import _lib
     c, graph, gs = _tile_case(mp, exp, bsz, nx, neighbors)
-    t = gs.tiles()
+    mp.lib().msmp_tune(b'tile_align', align)      # 1: periodic descriptors also where the tile does not divide the graph (short last tile per graph)
+    try:
+        t = gs.tiles()
+    finally:
+        mp.lib().msmp_tune(b'tile_align', 0)
     assert t is not None, 'the banded 1-D graphs of the four experiments must tile'
     desc, tile_node, tile_count, edge_slot, tile_halo = t
+    assert (desc.period_tiles > 0) == (bsz > 1 and (nx % desc.tile_nodes == 0 or align == 1)), (desc.tile_nodes, desc.period_tiles)
     tile_halo = tile_halo.cpu().numpy().reshape(-1, 4)
     tn, gn, n_tiles = desc.tile_nodes, desc.group_nodes, desc.n_tiles
     assert tn == 4 * gn
@@ -902,3 +908,24 @@ def test_integration_md_bindings_run(mp):
     scale = max(g.abs().max().item() for g in own)
     for a_, b_ in zip(grads, own):
         assert (a_ - b_).abs().max().item() < 1e-4 * scale
+
+
+def test_period_detection_refuses_batches_that_are_not_copies(mp):
+    """GraphStructure.period(): (nodes, edges) of one graph only when EVERY graph of the batch is the first one shifted -- same size,
+    same edges in the same CSR order.  A batch with one edge removed, a batch of unequal graphs and a single graph are not periodic
+    (they keep per-tile descriptors for the whole batch), and the tiled layer on such a batch equals the gather path."""
+    from msmp_pde_amd.graph import GraphStructure
+    c, graph, gs = _tile_case(mp, 'E2', 4, 100, 3)
+    assert gs.period() == (100, gs.n_edges // 4) and gs.tiles()[0].period_tiles == 5
+    ei = graph.edge_index
+    keep = torch.ones(ei.shape[1], dtype=torch.bool, device=ei.device)
+    keep[ei.shape[1] // 2 + 3] = False                     # one edge less in the third graph
+    gs2 = GraphStructure(ei[:, keep].contiguous(), graph.batch, graph.x.shape[0])
+    assert gs2.period() is None and gs2.tiles()[0].period_tiles == 0
+    n1 = 250                                               # graphs of 100, 100, 50 nodes
+    m = (ei[0] < n1) & (ei[1] < n1)
+    batch = torch.cat([torch.zeros(100), torch.ones(100), torch.full((50,), 2)]).long().to(ei.device)
+    gs3 = GraphStructure(ei[:, m].contiguous(), batch, n1)
+    assert gs3.period() is None
+    c1, g1, gs1 = _tile_case(mp, 'E2', 1, 100, 3)
+    assert gs1.period() is None and gs1.tiles()[0].period_tiles == 0
