@@ -510,6 +510,11 @@ int msmp_wide_gather_swish_f32(const float* p, const float* q, const int32_t* tg
 /* PyG aggr='mean' over CSR rows, any width */
 int msmp_wide_scatter_mean_f32(const float* msg, const int32_t* rowptr, int64_t n_nodes, int width, int ld, float* agg_out, msmp_stream_t stream);
 int msmp_wide_swish_f32(const float* x, int64_t n_floats, float* out, msmp_stream_t stream);
+/* The pointwise halves of one LEM time step at any hidden width (the GLU classes' encoder; the cell of experiments/models_gnn.py:285-342,
+ * SURVEY 8c), around the two recurrent GEMMs:  g [N, 3 width] = [y, x_t] W^T + b  ->  dtbar_out = dt sigmoid(g1),
+ * z <- (1 - dt sigmoid(g2)) z + dt sigmoid(g2) tanh(g3);  then with lin [N, width] = [z, x_t] Wz^T + bz:  y <- (1 - dtbar) y + dtbar tanh(lin). */
+int msmp_wide_lem_z_f32(const float* g, int64_t n_nodes, int width, float dt, float* z, float* dtbar_out, msmp_stream_t stream);
+int msmp_wide_lem_y_f32(const float* lin, const float* dtbar, int64_t n_floats, float* y, msmp_stream_t stream);
 /* gate_pre == NULL: out = InstanceNorm(main_pre); else out = (1 - tau) h + tau Swish(IN(main_pre)), tau = sigmoid(IN(gate_pre)) */
 int msmp_wide_norm_blend_f32(const float* h, const float* gate_pre, const float* main_pre, const int32_t* graph_ptr, int64_t n_graphs,
                              int width, int ld, float eps, float* out, msmp_stream_t stream);

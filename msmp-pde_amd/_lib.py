@@ -103,6 +103,8 @@ SIGNATURES = {
     'msmp_wide_gather_swish_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     'msmp_wide_scatter_mean_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     'msmp_wide_swish_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    'msmp_wide_lem_z_f32': (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    'msmp_wide_lem_y_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'msmp_wide_norm_blend_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p]),
     'msmp_timing_enable': (c_int, [c_int]),
     'msmp_timing_reset': (c_int, []),

@@ -54,6 +54,33 @@ __global__ __launch_bounds__(256) void wide_swish_kernel(const float* __restrict
     reinterpret_cast<f32x4*>(out)[i] = r;
 }
 
+// The LEM cell's pointwise halves at any hidden width (the GLU classes' encoder, experiments/models_gnn.py:285-342 with the published
+// cell: SURVEY 8c): the two recurrent GEMMs of a time step stay library calls, everything between them is ONE launch each instead of
+// ~20 PyTorch elementwise kernels per step (each a pass over [N, W] .. [N, 3 W]: 46 -> 24 ms per forward at 2048 graphs, W = 164).
+//   z-half:  g = [g1 | g2 | g3] [N, 3 W]:  dtbar = dt sigmoid(g1),  z <- (1 - dt sigmoid(g2)) z + dt sigmoid(g2) tanh(g3)
+//   y-half:  y <- (1 - dtbar) y + dtbar tanh(lin)
+__device__ __forceinline__ float wide_tanh(float x) {           // 1 - 2 / (1 + e^{2x}), exponent clamped like the fused kernels
+    const float e = msmp_exp2(fminf(x * 2.88539008177792681472f, 60.f));
+    return 1.0f - 2.0f * msmp_rcp(1.0f + e);
+}
+__global__ __launch_bounds__(256) void wide_lem_z_kernel(const float* __restrict__ g, long n, int w, float dt, float* __restrict__ z,
+                                                         float* __restrict__ dtbar) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * w) return;
+    const long r = i / w;
+    const int c = (int)(i - r * w);
+    const float* gr = g + (size_t)r * 3 * w;
+    const float d2 = dt * sigmoidf_(gr[w + c]);
+    dtbar[i] = dt * sigmoidf_(gr[c]);
+    z[i] = (1.0f - d2) * z[i] + d2 * wide_tanh(gr[2 * w + c]);
+}
+__global__ __launch_bounds__(256) void wide_lem_y_kernel(const float* __restrict__ lin, const float* __restrict__ dtbar, long n, float* __restrict__ y) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float d = dtbar[i];
+    y[i] = (1.0f - d) * y[i] + d * wide_tanh(lin[i]);
+}
+
 // One workgroup per graph, thread = (4-channel group cg = tid % ld4 ..., row slice): PyG InstanceNorm (biased variance, two passes)
 // of `main_pre` (and `gate_pre`), then  out = IN(main)   or   out = (1 - tau) h + tau Swish(IN(main)),  tau = sigmoid(IN(gate)).
 __global__ __launch_bounds__(256) void wide_norm_blend_kernel(const float* __restrict__ h, const float* __restrict__ gate_pre,
@@ -140,6 +167,21 @@ extern "C" int msmp_wide_scatter_mean_f32(const float* msg, const int32_t* rowpt
     hipLaunchKernelGGL(wide_scatter_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, msg, rowptr, (long)n_nodes,
                        ld / 4, agg_out);
     return check_launch("wide_scatter_mean_kernel");
+}
+
+extern "C" int msmp_wide_lem_z_f32(const float* g, int64_t n_nodes, int width, float dt, float* z, float* dtbar_out, msmp_stream_t stream) {
+    MSMP_REQUIRE(g && z && dtbar_out, MSMP_ERR_ARG, "msmp_wide_lem_z_f32: null pointer");
+    MSMP_REQUIRE(n_nodes > 0 && width > 0 && n_nodes * (int64_t)width < (1LL << 40), MSMP_ERR_ARG, "msmp_wide_lem_z_f32: bad sizes");
+    const long total = (long)n_nodes * width;
+    hipLaunchKernelGGL(wide_lem_z_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, (long)n_nodes, width, dt, z, dtbar_out);
+    return check_launch("wide_lem_z_kernel");
+}
+
+extern "C" int msmp_wide_lem_y_f32(const float* lin, const float* dtbar, int64_t n_floats, float* y, msmp_stream_t stream) {
+    MSMP_REQUIRE(lin && dtbar && y, MSMP_ERR_ARG, "msmp_wide_lem_y_f32: null pointer");
+    MSMP_REQUIRE(n_floats > 0, MSMP_ERR_ARG, "msmp_wide_lem_y_f32: bad size");
+    hipLaunchKernelGGL(wide_lem_y_kernel, dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lin, dtbar, (long)n_floats, y);
+    return check_launch("wide_lem_y_kernel");
 }
 
 extern "C" int msmp_wide_swish_f32(const float* x, int64_t n_floats, float* out, msmp_stream_t stream) {

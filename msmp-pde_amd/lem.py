@@ -45,6 +45,18 @@ class LEMcuda(nn.Module):
         # input projections for all steps at once (the recurrent part stays sequential)
         gx = torch.matmul(inputs, wx) + self.bias          # [T, N, 3H]
         lx = torch.matmul(inputs, zx) + self.bias_lin_z    # [T, N, H]
+        if inputs.is_cuda and inputs.dtype == torch.float32 and not torch.is_grad_enabled():
+            # inference at any width (the GLU classes): the two recurrent GEMMs stay library calls, the pointwise work between them is one
+            # HIP launch each (msmp_wide_lem_z_f32 / _y_f32) instead of ~20 elementwise kernels per time step
+            L = lib()
+            y, z = y.contiguous().clone(), z.contiguous().clone()
+            dt_bar = torch.empty_like(y)
+            for t in range(t_len):
+                g = torch.addmm(gx[t], y, wy)
+                check(L.msmp_wide_lem_z_f32(ptr(g), n, nh, float(self.dt), ptr(z), ptr(dt_bar), current_stream()), 'msmp_wide_lem_z_f32')
+                lin = torch.addmm(lx[t], z, zy)
+                check(L.msmp_wide_lem_y_f32(ptr(lin), ptr(dt_bar), n * nh, ptr(y), current_stream()), 'msmp_wide_lem_y_f32')
+            return (y, z) if return_state else y
         for t in range(t_len):
             g = torch.addmm(gx[t], y, wy)
             dt_bar = self.dt * torch.sigmoid(g[:, :nh])
