@@ -1011,6 +1011,14 @@ __device__ __forceinline__ void tail_rows_read(const float* buf, int row, int hh
     }
 }
 
+// a 16-KB weight chunk global -> LDS by LDS-DMA (lane-linear image, as wstage_store_linear writes it)
+__device__ __forceinline__ void wstage_dma(const float* __restrict__ chunk, float* buf, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(chunk + 4 * (tid + 256 * i)),
+                                         (__attribute__((address_space(3))) void*)(buf + 4 * (tid + 256 * i)), 16, 0, 0);
+}
+
 template <typename MidHook>
 __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, const float* __restrict__ h, const float* __restrict__ agg,
                                              const float* __restrict__ vars, long nc, int nv, const float* b3, const float* b4,
@@ -1019,20 +1027,21 @@ __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, cons
     // ACT_SCALE: the node rows and the Swish output enter the split GEMMs multiplied by 2^6, so that the fp16 low halves of small
     // activations stay normal (see tile_kernels.hip); every factor is a power of two folded into an existing constant.
     const float sc3 = scales[2] * TAIL_NODE_SCALE, inv3 = scales[6] * (TAIL_ACT_SCALE / TAIL_NODE_SCALE), sc4 = scales[3] * TAIL_ACT_SCALE;
-    WStage ws;
-    wstage_load(ws, w3s, tid);
+    // Weight chunks reach LDS by LDS-DMA (round 4; the staged image is lane-linear, i.e. exactly what global_load_lds_dwordx4 writes):
+    // no register round trip (16 VGPRs, 4 ds_write_b128 per thread and chunk); a chunk is requested into the buffer the PREVIOUS
+    // chunk's MFMAs read, free since the barrier that ended that iteration, and the barrier at the end of this one waits for it.
+    wstage_dma(w3s, lds, tid);
     float xv[8];
     half8 wvf[2][4];
     f32x16 z[4][1];
     acc_init_bias_scaled<1>(b3, sc3, hh, z);
-    wstage_store_linear(ws, lds, tid);
     __syncthreads();                // (with the vmcnt(0) of the LDS-DMA in flight: chunk 0 of the rows has landed)
     PROF_MARK(5);
     const int myrow = (tid >> 6) * 32 + c;
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
         if (ch < 7) tail_rows_issue(h, agg, n0, n1, ch + 1, rowbuf + ((ch + 1) & 1) * ROWBUF_FLOATS, tid);
-        wstage_load(ws, ch < 7 ? w3s + (size_t)(ch + 1) * SPLIT_CHUNK_FLOATS : w4t, tid);
+        wstage_dma(ch < 7 ? w3s + (size_t)(ch + 1) * SPLIT_CHUNK_FLOATS : w4t, lds + ((ch + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
         half8 bhi[1][2], blo[1][2];
         {
             f32x4 pf[4];
@@ -1060,7 +1069,6 @@ __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, cons
         PROF_MARK(6);
         mma_chunk_split<1>(lds + (ch & 1) * SPLIT_CHUNK_FLOATS, lane, bhi, blo, z);
         PROF_MARK(7);
-        wstage_store_linear(ws, lds + ((ch + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
         PROF_MARK(8);
         __syncthreads();
         PROF_MARK(9);
@@ -1121,7 +1129,7 @@ __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, cons
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        if (t < 3) wstage_load(ws, w4t + (size_t)(t + 1) * SPLIT_CHUNK_FLOATS, tid);
+        if (t < 3) wstage_dma(w4t + (size_t)(t + 1) * SPLIT_CHUNK_FLOATS, lds + ((t + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
         half8 zhi[1][2], zlo[1][2];
         split_acc_tile<1>(z[t], zhi, zlo);
         const half8* w = reinterpret_cast<const half8*>(lds + (t & 1) * SPLIT_CHUNK_FLOATS) + lane;
@@ -1135,10 +1143,7 @@ __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, cons
                 yT[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zlo[0][s], whi, yT[T], 0, 0, 0);
                 yT[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zhi[0][s], whi, yT[T], 0, 0, 0);
             }
-        if (t < 3) {
-            wstage_store_linear(ws, lds + ((t + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
-            __syncthreads();
-        }
+        if (t < 3) __syncthreads();
     }
 }
 
