@@ -38,28 +38,31 @@ with torch.no_grad():
         res[-S] = timed(lambda: [p.step() for p in parts], 30)       # the same sub-batches one after the other on one stream
     t1 = timed(whole.step, 60)
 with torch.no_grad():
-    # two sub-batches, each a hipGraph replay of its forward on its own stream
-    S = 2
-    parts = [bench.Workload(args, mp, dev, n_graphs // S, seed=50 + i) for i in range(S)]
-    streams = [torch.cuda.Stream() for _ in range(S)]
-    caps = []
-    for p, s in zip(parts, streams):
-        p.model = whole.model
-        p.first()
-        caps.append(p.model.capture(p.graph))
-    torch.cuda.synchronize()
-    def step_cap():
-        for p, cap, s in zip(parts, caps, streams):
-            with torch.cuda.stream(s):
-                step = 75 + 25 * (p.i % 7); p.i += 1
-                same = [step] * p.bsz
-                _, lab = p.case.creator.create_data(p.case.u_super, same)
-                g = p.case.creator.create_next_graph(p.graph, p.pred, lab, same)
-                p.pred = cap(g)
-    for s in streams: s.wait_stream(torch.cuda.current_stream())
-    timed(step_cap, 20)
-    t_cap = timed(step_cap, 100)
-    print(f'{n_graphs} graphs: 2 sub-batches on 2 streams, captured forwards: {t_cap:.3f} ms per step')
+    # S sub-batches, each a hipGraph replay of its forward on its own stream (the host issues ~6 launches per sub-batch and step instead of ~25)
+    for S in (1, 2, 3, 4, 6):
+        parts = [bench.Workload(args, mp, dev, n_graphs // S, seed=50 + 7 * S + i) for i in range(S)]
+        streams = [torch.cuda.Stream() for _ in range(S)]
+        caps = []
+        for p, s in zip(parts, streams):
+            p.model = whole.model
+            p.first()
+            caps.append(p.model.capture(p.graph))
+        torch.cuda.synchronize()
+        def step_cap():
+            for p, cap, s in zip(parts, caps, streams):
+                with torch.cuda.stream(s):
+                    step = 75 + 25 * (p.i % 7)
+                    src = p.x0 if p.i % 7 == 0 else p.pred
+                    p.i += 1
+                    same = [step] * p.bsz
+                    _, lab = p.case.creator.create_data(p.case.u_super, same)
+                    g = p.case.creator.create_next_graph(p.graph, src, lab, same)
+                    p.pred = cap(g)
+        for s in streams: s.wait_stream(torch.cuda.current_stream())
+        timed(step_cap, 20)
+        t_cap = timed(step_cap, 100)
+        print(f'{n_graphs} graphs: {S} sub-batches on {S} streams, captured forwards: {t_cap:.3f} ms per step', flush=True)
+        del caps, parts
 with torch.no_grad():
     whole.model.sub_batches = 2
     timed(whole.step, 10)
