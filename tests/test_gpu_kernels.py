@@ -929,3 +929,56 @@ def test_period_detection_refuses_batches_that_are_not_copies(mp):
     assert gs3.period() is None
     c1, g1, gs1 = _tile_case(mp, 'E2', 1, 100, 3)
     assert gs1.period() is None and gs1.tiles()[0].period_tiles == 0
+
+
+@pytest.mark.parametrize('sizes,reach', [((100, 37, 64, 5, 128, 1, 90), 3), ((128, 128, 17), 2), ((33,) * 9, 3)])
+def test_tiled_message_kernel_on_batches_of_unequal_graphs(mp, sizes, reach):
+    """Node tiles on a batch that is NOT copies of one graph (no periodic descriptor): banded chains of different lengths -- every node
+    connected to its neighbours within `reach` inside its own graph -- including graphs shorter than a tile, a single node without
+    edges and tiles that straddle graphs of different structure.  The folded tile kernel against the gather kernels and the
+    float64 oracle, and the tiled layer call against the untiled one."""
+    import ctypes
+    from msmp_pde_amd._lib import check, ptr, current_stream
+    from msmp_pde_amd.graph import GraphStructure
+    L = mp.lib()
+    src, tgt, batch, off = [], [], [], 0
+    for g, m in enumerate(sizes):
+        for i in range(m):
+            for d in range(-reach, reach + 1):
+                if d and 0 <= i + d < m:
+                    src.append(off + i + d); tgt.append(off + i)
+        batch += [g] * m
+        off += m
+    n = off
+    ei = torch.tensor([src, tgt], dtype=torch.int64).cuda()
+    gs = GraphStructure(ei, torch.tensor(batch).cuda(), n)
+    same_size = len(set(sizes)) == 1
+    assert (gs.period() is not None) == (same_size and len(sizes) > 1)
+    t = gs.tiles()
+    assert t is not None and (t[0].period_tiles > 0) == (gs.period() is not None and sizes[0] % t[0].tile_nodes == 0)
+    tw, nv, e = 25, 2, gs.n_edges
+    rng = np.random.default_rng(5)
+    sd = rand_layer_sd(rng, tw, nv)
+    blob = pack(mp, sd, tw, nv)
+    h = torch.tensor(rng.standard_normal((n, H)), dtype=torch.float32).cuda()
+    u = torch.tensor(rng.standard_normal((n, tw)) * 0.3, dtype=torch.float32).cuda()
+    pos = torch.tensor(rng.uniform(0, 1, n), dtype=torch.float32).cuda()
+    var = torch.tensor(rng.uniform(0, 1, (n, nv)), dtype=torch.float32).cuda()
+    P, Q = torch.empty(n, H, device='cuda'), torch.empty(n, H, device='cuda')
+    ref, folded = torch.empty(n, H, device='cuda'), torch.empty(n, H, device='cuda')
+    st = current_stream()
+    check(L.msmp_node_project_f32(ptr(h), ptr(u), ptr(pos), ptr(var), n, tw, nv, ptr(blob), ptr(P), ptr(Q), st), 'proj')
+    check(L.msmp_edge_aggregate_projected_f32(ptr(P), ptr(Q), ptr(gs.rowptr), ptr(gs.col), ptr(gs.tgt), n, e, gs.max_in_degree, tw, nv,
+                                              ptr(blob), ptr(ref), st), 'edge')
+    check(L.msmp_edge_aggregate_tiled_f32(ptr(h), ptr(u), ptr(pos), ptr(var), None, None, None, ptr(gs.rowptr), ctypes.byref(t[0]), n, e, tw, nv,
+                                          ptr(blob), ptr(folded), st), 'tiled folded')
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (folded - ref).abs().max().item() < 2e-6 * scale
+    p64 = O.layer_params({k: v.astype(np.float64) for k, v in sd.items()}, '')
+    ein = np.stack([gs.col.cpu().numpy()[:e], gs.tgt.cpu().numpy()[:e]])
+    msg = O.edge_messages(p64, h.double().cpu().numpy(), u.double().cpu().numpy(), pos.double().cpu().numpy()[:, None], var.double().cpu().numpy(), ein)
+    agg = O.scatter_mean(msg, ein[1], n)
+    err = np.abs(folded.double().cpu().numpy() - agg).max() / max(np.abs(agg).max(), 1e-30)
+    print(f'sizes {sizes} reach {reach}: tile_nodes {t[0].tile_nodes}, periodic {t[0].period_tiles > 0}, listed {bool(t[0].listed)}; folded tile kernel vs float64 {err:.2e}')
+    assert err < 1e-6
