@@ -37,6 +37,10 @@ constexpr int TILE_NCAP = MSMP_TILE_NCAP;
 constexpr int TILE_EDGES = MSMP_TILE_EDGES;
 constexpr int PQLD = H + 4;                       // LDS row stride of a staged P / Q row (floats): 33 x 16 B
 constexpr int BROW_T = 72;                        // halfs per staged fragment row: [hi 32 | lo 32] + 16 B pad (as node_proj's B tile)
+// chunk c of the fragment tile starts FRAG_SKEW halfs (16 banks) later than a plain [chunk][slot] array would put it: a thread's 16-lane
+// write group covers the 32-byte pieces of TWO consecutive chunks of one slot (32 rows = 1 152 dwords apart: the same banks without the skew)
+constexpr int FRAG_SKEW = 32;
+__device__ __forceinline__ int frag_row(int chunk, int slot) { return (chunk * 32 + slot) * BROW_T + chunk * FRAG_SKEW; }
 // Activations enter the fp16-split GEMMs multiplied by 2^6.  The low half of a value x is fp16(x - fp16(x)) ~ 2^-11 x: for
 // |x| < 0.25 it falls into the fp16 subnormals (quantum 6e-8), i.e. the split then carries x with an ABSOLUTE error of 3e-8
 // instead of a relative 2^-23.  Hidden states right behind the encoder and the pre-activations of the first layers are that
@@ -267,7 +271,7 @@ constexpr int WBUF_FLOATS = 2 * WHALF_FLOATS;
 constexpr int TILE_MAIN_FLOATS = WBUF_FLOATS + 2 * TILE_NCAP * PQLD;      // 12 544 floats = 50 176 B
 constexpr int TILE_LUT_FLOATS = 32;                                       // 16 entries x 8 B: nibble -> four fp16 0 / 1 (the mean's selection matrix)
 constexpr int TILE_LDS_FLOATS = TILE_MAIN_FLOATS + TILE_LUT_FLOATS;       // 50 304 B: three workgroups per CU
-static_assert(8 * 32 * BROW_T * 2 <= TILE_MAIN_FLOATS * 4, "fragment tile of the folded projections must fit");
+static_assert((8 * 32 * BROW_T + 8 * FRAG_SKEW) * 2 <= TILE_MAIN_FLOATS * 4, "fragment tile of the folded projections must fit");
 
 struct WHalf {
     f32x4 r[2];
@@ -455,7 +459,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
                 split_node_pair(hv[i][0], hv[i][1], h01, l01);
                 split_node_pair(hv[i][2], hv[i][3], h23, l23);
                 const int piece = tid & 31;
-                _Float16* row = bt + ((piece >> 3) * 32 + (tid >> 5) + 8 * i) * BROW_T + 4 * (piece & 7);
+                _Float16* row = bt + frag_row(piece >> 3, (tid >> 5) + 8 * i) + 4 * (piece & 7);
                 *reinterpret_cast<half4v*>(row) = half4v{h01[0], h01[1], h23[0], h23[1]};
                 *reinterpret_cast<half4v*>(row + 32) = half4v{l01[0], l01[1], l23[0], l23[1]};
             }
@@ -472,8 +476,8 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
                         qh[m] = ph[m] * nm;
                         ql2[m] = pl2[m] * nm;
                     }
-                    _Float16* rp_ = bt + ((4 + 2 * jc) * 32 + (tid >> 3)) * BROW_T + 4 * g;
-                    _Float16* rq_ = bt + ((5 + 2 * jc) * 32 + (tid >> 3)) * BROW_T + 4 * g;
+                    _Float16* rp_ = bt + frag_row(4 + 2 * jc, tid >> 3) + 4 * g;
+                    _Float16* rq_ = bt + frag_row(5 + 2 * jc, tid >> 3) + 4 * g;
                     *reinterpret_cast<half4v*>(rp_) = half4v{ph[0][0], ph[0][1], ph[1][0], ph[1][1]};
                     *reinterpret_cast<half4v*>(rp_ + 32) = half4v{pl2[0][0], pl2[0][1], pl2[1][0], pl2[1][1]};
                     *reinterpret_cast<half4v*>(rq_) = half4v{qh[0][0], qh[0][1], qh[1][0], qh[1][1]};
@@ -497,7 +501,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
             for (int m = 0; m < 4; ++m) { accP[4 * q + m] = bv[m] * sc; accQ[4 * q + m] = 0.f; }
         }
         auto afrag = [&](int ch, half8 (&ahi)[2], half8 (&alo)[2]) {
-            const _Float16* row = bt + (ch * 32 + c) * BROW_T + 8 * hh;
+            const _Float16* row = bt + frag_row(ch, c) + 8 * hh;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 ahi[s] = *reinterpret_cast<const half8*>(row + 16 * s);
