@@ -5,6 +5,10 @@
 
 namespace msmp {
 
+// a wave-uniform, read-only fp32 word (the 2^s scales of the packed layer): read through the constant address space, i.e. as a scalar load
+// that the compiler may issue early and keep -- as a plain global load it was re-issued after every barrier and waited for at once
+__device__ __forceinline__ float uniform_ro(const float* p, int i) { return ((const __attribute__((address_space(4))) float*)p)[i]; }
+
 struct WStage {
     f32x4 r[4];
 };

@@ -1026,7 +1026,7 @@ __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, cons
                                              int tid, int lane, int c, int hh, f32x16 (&yT)[4], MidHook mid_hook, bool center, float* zref PROF_ARGS) {
     // ACT_SCALE: the node rows and the Swish output enter the split GEMMs multiplied by 2^6, so that the fp16 low halves of small
     // activations stay normal (see tile_kernels.hip); every factor is a power of two folded into an existing constant.
-    const float sc3 = scales[2] * TAIL_NODE_SCALE, inv3 = scales[6] * (TAIL_ACT_SCALE / TAIL_NODE_SCALE), sc4 = scales[3] * TAIL_ACT_SCALE;
+    const float sc3 = uniform_ro(scales, 2) * TAIL_NODE_SCALE, inv3 = uniform_ro(scales, 6) * (TAIL_ACT_SCALE / TAIL_NODE_SCALE), sc4 = uniform_ro(scales, 3) * TAIL_ACT_SCALE;
     // Weight chunks reach LDS by LDS-DMA (round 4; the staged image is lane-linear, i.e. exactly what global_load_lds_dwordx4 writes):
     // no register round trip (16 VGPRs, 4 ds_write_b128 per thread and chunk); a chunk is requested into the buffer the PREVIOUS
     // chunk's MFMAs read, free since the barrier that ended that iteration, and the barrier at the end of this one waits for it.
@@ -1215,10 +1215,13 @@ __device__ __forceinline__ void tile_t_instance_norm(f32x16 (&x)[4], int wave, i
 
 template <bool GATED>
 __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * SPLIT_CHUNK_FLOATS];
-    __shared__ __attribute__((aligned(16))) float rowbuf[2 * ROWBUF_FLOATS];        // two staged 32-column chunks of the graph's node rows
-    __shared__ float part[8 * H];
-    __shared__ float tot[H];
+    // ONE LDS object: with several __shared__ arrays the compiler tags every access with its array and then makes each ds_read of an
+    // array wait (vmcnt) for the LDS-DMA into that array issued just before it -- the next chunk's, i.e. the prefetch was waited for at once
+    __shared__ __attribute__((aligned(16))) float smem[2 * SPLIT_CHUNK_FLOATS + 2 * ROWBUF_FLOATS + 9 * H];
+    float* const lds = smem;
+    float* const rowbuf = smem + 2 * SPLIT_CHUNK_FLOATS;        // two staged 32-column chunks of the graph's node rows
+    float* const part = rowbuf + 2 * ROWBUF_FLOATS;
+    float* const tot = part + 8 * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     const int n0 = a.graph_ptr[blockIdx.x], n1 = a.graph_ptr[blockIdx.x + 1];
@@ -1234,7 +1237,7 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
         head_compute(rowbuf, n0, n1, a.h, a.agg[1], a.vars, nc, a.nv, a.b3[1], a.b4[1], a.w3vh[1], a.w3s[1], a.w4t[1], a.scales[1], lds, tid, lane,
                      c, hh, tau, [&] { tail_rows_issue(a.h, a.agg[0], n0, n1, 0, rowbuf, tid); }, true, tot PROF_PASS);
         PROF_MARK(0);
-        tile_t_instance_norm(tau, wave, cnt, a.scales[1][7] * (1.0f / TAIL_ACT_SCALE), a.eps, part, tot, tid, c, hh, a.status);
+        tile_t_instance_norm(tau, wave, cnt, uniform_ro(a.scales[1], 7) * (1.0f / TAIL_ACT_SCALE), a.eps, part, tot, tid, c, hh, a.status);
 #pragma unroll
         for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -1273,7 +1276,7 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
         for (int r = 0; r < 16; ++r) mx = fmaxf(fmaxf(fmaxf(fabsf(hx[r][0]), fabsf(hx[r][1])), fmaxf(fabsf(hx[r][2]), fabsf(hx[r][3]))), mx);
         if (mx > NODE_RANGE) status_raise(a.status, MSMP_STATUS_NODE_SATURATED);
     }
-    float unit = a.scales[0][7] * (1.0f / TAIL_ACT_SCALE);
+    float unit = uniform_ro(a.scales[0], 7) * (1.0f / TAIL_ACT_SCALE);
     if (!GATED && a.mode != MSMP_LAYER_LIN) {
 #pragma unroll
         for (int T = 0; T < 4; ++T)

@@ -492,7 +492,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
         // i.e. a lane holds four CONSECUTIVE channels of its slot per register quad: the P / Q rows go to LDS as 16-byte pieces
         // (8 ds_write_b128; round 3: 32 ds_write_b32 + 32 multiplications) and keep the accumulators' scale 2^s 2^8, which the
         // activation folds into its constants.
-        const float sc = a.scales[0] * NODE_SCALE;
+        const float sc = uniform_ro(a.scales, 0) * NODE_SCALE;
         f32x16 accP, accQ;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -556,7 +556,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
     // of a tile are then exactly the B fragment of K step s of one more MFMA over the wave's 32 edges: the per-target sum.
     f32x16 y[4];
     {
-        const float s2 = a.scales[1] * ACT_SCALE;
+        const float s2 = uniform_ro(a.scales, 1) * ACT_SCALE;
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
             const float bv = a.b2[32 * T + c] * s2;
@@ -574,8 +574,8 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
     };
     float zt[8];
     // the rows carry x_raw = g x64 (g = 2^s 2^8 / 2^6, a power of two; 1 for staged rows):  z = 64 Swish(x) = x_raw / (g (1 + e^-x))
-    const float act_g = FOLD ? a.scales[0] * (NODE_SCALE / ACT_SCALE) : 1.0f;
-    const float act_ct = (-1.44269504088896340736f / ACT_SCALE) / act_g;
+    const float act_g = FOLD ? uniform_ro(a.scales, 0) * (NODE_SCALE / ACT_SCALE) : 1.0f;
+    const float act_ct = (-1.44269504088896340736f / ACT_SCALE) * (FOLD ? uniform_ro(a.scales, 4) * (ACT_SCALE / NODE_SCALE) : 1.0f);     // / act_g, a power of two: exact either way
     auto act_slice = [&](int i) {        // i = 0..3: piece j = i >> 1, elements 2 (i & 1), + 1
         const int j = i >> 1, m0 = 2 * (i & 1);
 #if MSMP_PRECISE_ACT
@@ -638,8 +638,8 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
     // straight from the accumulator registers, fp32 accumulation, then x 1 / (64 deg).  Same arithmetic in the same order per value
     // as the straight-line form of round 3: bit-identical.
     // m64 = 64 Swish(y).  The accumulators hold yy = 2^s 64 y; with kinv = 2^s:  m64 = yy / (kinv (1 + e^-y)).
-    const float kinv = a.scales[1];
-    const float inv2 = a.scales[5] * (1.0f / ACT_SCALE);
+    const float kinv = uniform_ro(a.scales, 1);
+    const float inv2 = uniform_ro(a.scales, 5) * (1.0f / ACT_SCALE);
     const float cexp = -1.44269504088896340736f * inv2;
     auto swish2 = [&](int T, int r0, int r1) {
 #pragma unroll
