@@ -142,7 +142,10 @@ using half2 = __attribute__((ext_vector_type(2))) _Float16;
 // lo = fp16(x - float(hi)) for a pair: one mixed-precision FMA per value (x - hi is exact in fp32, so this equals the
 // convert-back / subtract / convert sequence bit for bit, in 2 instructions instead of 5).  Inline asm is invisible to the
 // compiler's hazard recogniser: x and hi must not be the direct result of an MFMA or a transcendental instruction
-// (every caller passes loaded values or the output of ordinary VALU arithmetic).
+// (every caller passes loaded values or the output of ordinary VALU arithmetic), and the RESULT must not be read by an MFMA
+// as SrcA / SrcB in the next instruction slot: gfx950 does not interlock VALU write -> MFMA operand read (scripts/micro/mfma_raw.hip:
+// acc 12-14 of 16 with no instruction in between, right with one s_nop; the compiler pads its own instructions).  split8 ends
+// with mfma_operand_guard for that reason.
 __device__ __forceinline__ half2 split_lo_pair(half2 hi, f32x2 x) {
     half2 lo;
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
@@ -150,6 +153,9 @@ __device__ __forceinline__ half2 split_lo_pair(half2 hi, f32x2 x) {
         : "=&v"(lo) : "v"(hi), "v"(x[0]), "v"(x[1]));
     return lo;
 }
+
+// orders every later reader of `v` behind two wait states after the inline-asm writes above it (see split_lo_pair)
+__device__ __forceinline__ void mfma_operand_guard(half8& v) { asm volatile("s_nop 1" : "+v"(v)); }
 
 __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
 #pragma unroll
@@ -162,6 +168,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo
         lo[j] = l[0];
         lo[j + 1] = l[1];
     }
+    mfma_operand_guard(lo);
 }
 
 // Per-node scalar columns (the <= 8 equation variables) enter a split GEMM as two K=16 fp16 MFMAs.  K slot s pairs
