@@ -171,6 +171,34 @@ __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo
     mfma_operand_guard(lo);
 }
 
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+// hi = fp16(256 x), lo = fp16(256 x - hi) for a pair of node-row values: four mixed-precision FMAs (the scaling is exact, the
+// difference is formed exactly inside the FMA: the same bits as multiply / convert / convert back / subtract / convert, which took
+// eleven instructions with the saturating clamp round 3 had here).  No clamp: |x| >= 256 becomes an fp16 infinity, every product with
+// it is Inf / NaN, the aggregate of every target that reads the row is not finite and the epilogue raises the status word (and
+// Solver.forward evaluates the forward again on the exact-fp32 kernels) -- nothing saturates silently.
+__device__ __forceinline__ void split_node_pair(float x0, float x1, half2v& hi, half2v& lo) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo) : "v"(x0), "v"(x1), "s"(256.0f));
+}
+
+// eight node-row values -> B fragments (hi, lo) of one K = 16 step, scaled by 2^8: split_node_pair four times, both results guarded
+__device__ __forceinline__ void split8_node(const float (&x)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        half2v h, l;
+        split_node_pair(x[j], x[j + 1], h, l);
+        hi[j] = h[0];
+        hi[j + 1] = h[1];
+        lo[j] = l[0];
+        lo[j + 1] = l[1];
+    }
+    asm volatile("s_nop 1" : "+v"(hi), "+v"(lo));      // mfma_operand_guard for both
+}
+
 // Per-node scalar columns (the <= 8 equation variables) enter a split GEMM as two K=16 fp16 MFMAs.  K slot s pairs
 //   s in [0,8): w_hi[f] x_hi[f]     [8,16): w_hi[f] x_lo[f]     [16,24): w_lo[f] x_hi[f]     [24,32): zero      (f = s & 7)
 // so the node side needs no indexing: k-step 0 is (x_hi | x_lo) on the (hh = 0 | 1) lanes, k-step 1 is (x_hi | 0).

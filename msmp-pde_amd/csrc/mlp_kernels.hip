@@ -1049,12 +1049,12 @@ __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, cons
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const f32x4 v0 = pf[2 * s], v1 = pf[2 * s + 1];
-                // (the two-instruction v_fma_mix split of the tile kernel's stage is NOT used here: it is inline asm, invisible to the
-                // hazard recogniser, and in this loop it would overwrite B-fragment registers that the previous chunk's MFMAs are
-                // still reading -- measured in round 4: run-to-run differences of 1e-1 in the layer output)
-                const float v[8] = {tail_node_scaled(v0[0]), tail_node_scaled(v0[1]), tail_node_scaled(v0[2]), tail_node_scaled(v0[3]),
-                                    tail_node_scaled(v1[0]), tail_node_scaled(v1[1]), tail_node_scaled(v1[2]), tail_node_scaled(v1[3])};
-                split8(v, bhi[0][s], blo[0][s]);
+                // hi = fp16(256 x), lo = fp16(256 x - hi) as four mixed-precision FMAs per pair (split_node_pair; no clamp: |x| >= 256 becomes
+                // an fp16 infinity, the norm's statistics are not finite and the status word is raised -- tile_kernels.hip).  Round 4 first
+                // measured this form as nondeterministic: the inline asm's results reached an MFMA in the next slot, which gfx950 does not
+                // interlock (profiles/r04N_mfma_operand_hazard.md); split8_node ends with the guard.
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                split8_node(v, bhi[0][s], blo[0][s]);
             }
         }
         if (ch == 5) {      // the variables and their slot fragments are consumed after the k loop: issued two chunks ahead

@@ -293,20 +293,7 @@ __device__ __forceinline__ void whalf_dma(const float* __restrict__ half_chunk, 
                                          (__attribute__((address_space(3))) void*)(buf + 4 * (tid + 256 * i)), 16, 0, 0);
 }
 
-using half2v = __attribute__((ext_vector_type(2))) _Float16;
 using half4v = __attribute__((ext_vector_type(4))) _Float16;
-// hi = fp16(256 x), lo = fp16(256 x - hi) for a pair of node-row values: four mixed-precision FMAs (the scaling is exact, the
-// difference is formed exactly inside the FMA: the same bits as multiply / convert / convert back / subtract / convert, which took
-// eleven instructions with the saturating clamp round 3 had here).  No clamp: |x| >= 256 becomes an fp16 infinity, every product with
-// it is Inf / NaN, the aggregate of every target that reads the row is not finite and the epilogue raises the status word (and
-// Solver.forward evaluates the forward again on the exact-fp32 kernels) -- nothing saturates silently.
-__device__ __forceinline__ void split_node_pair(float x0, float x1, half2v& hi, half2v& lo) {
-    asm("v_fma_mixlo_f16 %0, %2, %4, 0 op_sel_hi:[0,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %3, %4, 0 op_sel_hi:[0,0,0]\n\t"
-        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(hi), "=&v"(lo) : "v"(x0), "v"(x1), "s"(NODE_SCALE));
-}
 
 template <int MODE, bool LISTED>
 __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
