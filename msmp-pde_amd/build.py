@@ -28,7 +28,7 @@ SOURCES = {  # file -> extra flags
     'decoder_kernel.hip': [],
     'graph_kernels.hip': ['-ffp-contract=off'],   # float64 distance compares must round like the host's
 }
-PROF = {'lem': ['-DMSMP_PROF_LEM=1'], 'tile': ['-DMSMP_PROF_TILE=1'], '1': ['-DMSMP_PROF=1'], 'edge': ['-DMSMP_PROF=1', '-DMSMP_PROF_EDGE=1'], 'proj': ['-DMSMP_PROF=1', '-DMSMP_PROF_PROJ=1']}.get(os.environ.get('MSMP_PROF', ''), [])     # phase counters in the tail kernel (scripts/prof_tail.py)
+PROF = {'gw': ['-DMSMP_PROF_GW=1'], 'lem': ['-DMSMP_PROF_LEM=1'], 'tile': ['-DMSMP_PROF_TILE=1'], '1': ['-DMSMP_PROF=1'], 'edge': ['-DMSMP_PROF=1', '-DMSMP_PROF_EDGE=1'], 'proj': ['-DMSMP_PROF=1', '-DMSMP_PROF_PROJ=1']}.get(os.environ.get('MSMP_PROF', ''), [])     # phase counters in the tail kernel (scripts/prof_tail.py)
 COMMON = PROF + ([f'-DMSMP_LOLO={LOLO}'] if LOLO else []) + ([f'-DMSMP_TILE_VARIANT={VARIANT}'] if VARIANT else []) + (['-DMSMP_PRECISE_ACT=1'] if PRECISE else []) + ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
           '-fvisibility=hidden', '-fvisibility-inlines-hidden',
           '-I', os.path.join(ROOT, 'include'), '-I', CSRC]

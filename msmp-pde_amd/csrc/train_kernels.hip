@@ -245,6 +245,11 @@ __device__ __forceinline__ void gw_load(const GradWeightJob& j, const float* aco
             const float v = bcol4[row * bld4];
             r.b4[i] = FULL || i < rlim ? v : 0.f;
         }
+    } else {
+        // defined on both paths: left untouched here, r.b4 is merged with its old value behind the branch by copies that wait for the
+        // loads above (vmcnt(0) with the whole block's loads the youngest in flight: the prefetch was waited for where it was issued)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.b4[i] = 0.f;
     }
 }
 __device__ __forceinline__ void gw_publish(const float (&b)[8], float keep, float ones, u32x4* frag_tile, int lane) {
@@ -270,6 +275,17 @@ __device__ __forceinline__ void gw_mma(const Bf3& a3, const u32x4* frags, int la
     }
 }
 
+// Phase profile (build with MSMP_PROF=gw; scripts/prof_gw.py): cycle sums of wave 0 of every 8th workgroup with at least 100 blocks
+#if MSMP_PROF_GW
+__device__ unsigned long long g_prof_gw[8];
+#define GWP_DECL long long gp[5] = {0, 0, 0, 0, 0}; long long gt = __builtin_readcyclecounter();
+#define GWP(i) do { const long long t_ = __builtin_readcyclecounter(); gp[i] += t_ - gt; gt = t_; } while (0)
+#define GWP_FLUSH if (wave == 0 && lane == 0 && n_blocks >= 100 && (split & 7) == 0) { for (int i_ = 0; i_ < 5; ++i_) atomicAdd(&g_prof_gw[i_], (unsigned long long)gp[i_]); atomicAdd(&g_prof_gw[6], (unsigned long long)n_blocks); atomicAdd(&g_prof_gw[7], 1ull); }
+#else
+#define GWP_DECL
+#define GWP(i)
+#define GWP_FLUSH
+#endif
 __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int split, int wave, int lane, u32x4* frags /* LDS [2][GW_FRAG_U4] */) {
     const int m = lane & 31, kk = lane >> 5;
     f32x16 acc[GW_NT];
@@ -293,27 +309,58 @@ __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int spl
     const float* bcol4 = colptr(4, keep4, ones4, bld4);
     const int n_blocks = (r1 - r0 + 15) / 16;            // the last one may be ragged: it takes the predicated loads
     const int n_full = (r1 - r0) / 16;
+#if MSMP_TILE_VARIANT == 31
+    GwRegs cur, nxt, nx2;
+#else
     GwRegs cur, nxt;
+#endif
     auto load_block = [&](int blk, GwRegs& dst) {
         const int rb = r0 + 16 * blk + 8 * kk;
         if (blk < n_full) gw_load<true>(j, acol, bcol, bld, bcol4, bld4, (blk & 3) == wave, rb, 8, dst);
         else gw_load<false>(j, acol, bcol, bld, bcol4, bld4, (blk & 3) == wave, min(rb, r1 - 1), r1 - rb, dst);
     };
+    GWP_DECL
     if (n_blocks > 0) load_block(0, cur);
+#if MSMP_TILE_VARIANT == 31
+    if (n_blocks > 1) load_block(1, nxt);
+#endif
+#if MSMP_TILE_VARIANT != 32
+    // The first block's values are pinned in registers HERE (an empty asm that "modifies" them: the loads must have landed).  Without it
+    // the loop header inherits "loads pending on cur" from this prologue, and the wait the compiler places at the top of the loop for the
+    // first trip (vmcnt(14) ... vmcnt(0) through the publish phase) is executed on EVERY trip -- where the youngest loads are the next
+    // block's prefetch, issued a few instructions earlier: every block waited for its own prefetch (round 4 phase profile: 2 640 of
+    // 5 000 cycles per block).
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(cur.a[i]), "+v"(cur.b[i]), "+v"(cur.b4[i]));
+#endif
     __builtin_amdgcn_sched_barrier(0);
     for (int blk = 0; blk < n_blocks; ++blk) {
+#if MSMP_TILE_VARIANT == 31
+        if (blk + 2 < n_blocks) load_block(blk + 2, nx2);
+#else
         if (blk + 1 < n_blocks) load_block(blk + 1, nxt);
+#endif
         __builtin_amdgcn_sched_barrier(0);               // all loads of the next block are requested before this block's work
+        GWP(0);
         u32x4* fb = frags + (size_t)(blk & 1) * GW_FRAG_U4;
         gw_publish(cur.b, keep, ones, fb + (size_t)wave * 3 * 64, lane);
         if ((blk & 3) == wave) gw_publish(cur.b4, keep4, ones4, fb + (size_t)4 * 3 * 64, lane);
         const Bf3 a3 = split_bf16x3(cur.a);
+        GWP(1);
         __syncthreads();                                 // fragments of this block visible; the other buffer is free for the next block
+        GWP(2);
         gw_mma(a3, fb, lane, acc);
         __builtin_amdgcn_sched_barrier(0);
+        GWP(3);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { cur.a[i] = nxt.a[i]; cur.b[i] = nxt.b[i]; cur.b4[i] = nxt.b4[i]; }
+#if MSMP_TILE_VARIANT == 31
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { nxt.a[i] = nx2.a[i]; nxt.b[i] = nx2.b[i]; nxt.b4[i] = nx2.b4[i]; }
+#endif
     }
+    GWP(4);
+    GWP_FLUSH
     float* p = j.partial + (size_t)split * H * j.ldp + j.c0;
 #pragma unroll
     for (int t = 0; t < GW_NT; ++t)
@@ -322,7 +369,11 @@ __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int spl
             if (j.c0 + 32 * t < j.ldp) p[(size_t)(32 * wave + acc_row(r, kk)) * j.ldp + 32 * t + m] = acc[t][r];
 }
 
+#if MSMP_TILE_VARIANT == 31
+__global__ __launch_bounds__(256, 2) void grad_weight_kernel(GradWeightArgs a) {
+#else
 __global__ __launch_bounds__(256, 3) void grad_weight_kernel(GradWeightArgs a) {
+#endif
     int ji = 0;
 #pragma unroll
     for (int i = 1; i < GW_MAX_UNITS; ++i)
@@ -361,6 +412,12 @@ static int gw_rows_per_split(int64_t rows) {
 
 }  // namespace msmp
 
+#if MSMP_PROF_GW
+extern "C" __attribute__((visibility("default"))) int msmp_debug_prof_gw(unsigned long long* out8, int reset) {
+    if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(msmp::g_prof_gw), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(msmp::g_prof_gw), 8 * sizeof(unsigned long long));
+}
+#endif
 extern "C" int64_t msmp_grad_weights_workspace_floats(int n_jobs, const int64_t* rows, const int* k2) {
     if (n_jobs < 1 || n_jobs > GW_MAX_JOBS || !rows || !k2) return -1;
     int64_t total = 0;
