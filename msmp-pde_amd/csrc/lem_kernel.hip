@@ -866,6 +866,9 @@ __global__ __launch_bounds__(512) void lem_encoder_ws3_kernel(LemWsArgs a) {
     auto half_m = [&](auto Xc) {
         constexpr int X = decltype(Xc)::value;
         half8 bx[M];
+        // the step input fetched at the head of the PREVIOUS half-slot is first touched here: without the fence the compiler hoists its
+        // fp16 split into that vector half (a few dozen instructions behind the load) and the half stalls on the load's latency
+        __builtin_amdgcn_sched_barrier(0);
         lem_ws_slots<P>(xn, hh, bx);
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxw[0], bx[0], zero, 0, 0, 0);
