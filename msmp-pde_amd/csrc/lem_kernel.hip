@@ -737,6 +737,40 @@ __device__ unsigned long long g_prof_lem[16];
 template <bool SAME, int OFF0, int OFF1>
 __device__ __forceinline__ void lem_ws3_gemm2(const half8 (&w0)[4][2][2], const half8 (&w1)[4][2][2], const char* b0, const char* b1,
                                               f32x16& acc0, f32x16& acc1) {
+    if (!SAME) {
+        // role B reads two different state tiles (y for acc0, z for acc1): sixteen chains of three MFMAs, each behind its own fragment
+        // pair.  The hi fragment of chain n + 1 is requested before chain n's MFMAs, the lo fragment as soon as chain n's second MFMA has
+        // consumed its own (4 registers more than the plain form, no chain waits for LDS).  Same products in the same order per accumulator.
+        constexpr int FB = 64 * 16;
+        auto frag = [&](int n, int plane) -> half8 {        // chain n = 2 * (kt * 2 + s) + (0: acc0 / y, 1: acc1 / z)
+            const int f = (n >> 1) * 2 + plane;
+            return (n & 1) ? *reinterpret_cast<const half8*>(b1 + OFF1 + f * FB) : *reinterpret_cast<const half8*>(b0 + OFF0 + f * FB);
+        };
+        half8 h = frag(0, 0), l = frag(0, 1);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int kt = n >> 2, s = (n >> 1) & 1;
+            half8 hn = h, ln = l;
+            if (n < 15) hn = frag(n + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (n & 1) {
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kt][s][1], h, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kt][s][0], l, acc1, 0, 0, 0);
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][1], h, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][0], l, acc0, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (n < 15) ln = frag(n + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (n & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kt][s][0], h, acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kt][s][0], h, acc0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            h = hn;
+            l = ln;
+        }
+        return;
+    }
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
