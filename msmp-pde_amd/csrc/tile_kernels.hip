@@ -342,6 +342,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
     int rp_lo = rp[rp_row], rp_hi = rp[rp_row + 1];
     int er0 = 0, edeg = 0;
     auto edge_ranges = [&]() {           // called once the stage's own loads are out (and about to be waited for anyway)
+        __builtin_amdgcn_sched_barrier(0);       // (the copies into the asm's operands carry the wait for rp: they must not be hoisted above the loads)
         asm volatile("" : "+v"(rp_lo), "+v"(rp_hi));
         er0 = rp_lo - rp_base;
         edeg = c < gl - gf ? rp_hi - rp_lo : 0;
@@ -355,6 +356,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
     const float* prow = pl + (sl & 255) * PQLD + 4 * hh;
     const float* qrow = ql + ((sl >> 8) & 255) * PQLD + 4 * hh;
 
+    float b2v[4];
     // nodes of the slots this thread stages: rows (tid >> 5) + 8 i of h (or P / Q), row tid >> 3 of the feature columns
     int rnode[4], fnode;
     if (LISTED) {
@@ -382,6 +384,8 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
             pv[i] = *reinterpret_cast<const f32x4*>(a.P + (size_t)rnode[i] * H + 4 * piece) * ACT_SCALE;
             qv[i] = *reinterpret_cast<const f32x4*>(a.Q + (size_t)rnode[i] * H + 4 * piece) * ACT_SCALE;
         }
+#pragma unroll
+        for (int T = 0; T < 4; ++T) b2v[T] = a.b2[32 * T + c];
         edge_ranges();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -403,6 +407,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
             return *reinterpret_cast<const half8*>(base + woff);
         };
         half8 wp[3][2][2], wq[3][2][2];
+        f32x4 b1v[4];
         auto wload = [&](int i) {
             const int chp = i < 4 ? i : 8, chq = i < 4 ? 4 + i : (ntail > 1 ? 9 : 8);
 #pragma unroll
@@ -417,13 +422,16 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
             const int g = tid & 7;
             float tx[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             if (packed_feat) {
+                // loaded on BOTH sides of `jc < ntail` (a second copy of piece 0 where there is no second chunk) and selected afterwards: as a
+                // load inside the branch, the value was merged with the zeros of the other side by a copy right behind it, and that copy
+                // waited (vmcnt(0)) for every row load issued above before the weight prefetches below could be requested
 #pragma unroll
-                for (int jc = 0; jc < 2; ++jc)
-                    if (jc < ntail) {
-                        const f32x4 fv = *reinterpret_cast<const f32x4*>(a.feat + (size_t)fnode * (32 * ntail) + 32 * jc + 4 * g);
+                for (int jc = 0; jc < 2; ++jc) {
+                    const bool on = jc < ntail;
+                    const f32x4 fv = *reinterpret_cast<const f32x4*>(a.feat + (size_t)fnode * (32 * ntail) + 32 * (on ? jc : 0) + 4 * g);
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) tx[jc][m] = fv[m];
-                    }
+                    for (int m = 0; m < 4; ++m) tx[jc][m] = on ? fv[m] : 0.f;
+                }
             } else {
 #pragma unroll
                 for (int jc = 0; jc < 2; ++jc)
@@ -437,6 +445,11 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
                         }
                     }
             }
+            // message_net_1's bias for the P accumulators: requested with this batch, AHEAD of the weight chunks (loads complete in order:
+            // the first MFMA then waits for the bias and chunk 0 only).  Read where the projection starts, behind the stage's barrier,
+            // it was waited for ten instructions behind its request, in the middle of the MFMA stream.
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b1v[q] = *reinterpret_cast<const f32x4*>(a.b1 + 32 * wave + 8 * q + 4 * hh);
             wload(0);                                // the projection's first two weight chunks: behind the row loads
             wload(1);
             edge_ranges();
@@ -483,7 +496,7 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
         f32x16 accP, accQ;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b1 + 32 * wave + 8 * q + 4 * hh);
+            const f32x4 bv = b1v[q];
 #pragma unroll
             for (int m = 0; m < 4; ++m) { accP[4 * q + m] = bv[m] * sc; accQ[4 * q + m] = 0.f; }
         }
@@ -525,6 +538,8 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
             }
         }
         TPROF(1);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) b2v[T] = a.b2[32 * T + c];      // message_net_2's bias: requested two barriers ahead of the accumulator initialisation
         __syncthreads();                             // every wave is done with the fragment tile: the P / Q rows and the weight buffer may be written
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -546,10 +561,12 @@ __device__ __forceinline__ void edge_tile_body(const TileArgs& a, float* lds) {
         const float s2 = uniform_ro(a.scales, 1) * ACT_SCALE;
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
-            const float bv = a.b2[32 * T + c] * s2;
+            float bv = b2v[T] * s2;
+            asm volatile("" : "+v"(bv));         // consumed HERE, ahead of the K loop's first LDS-DMA: a wait placed behind the DMA is vmcnt(0)
 #pragma unroll
             for (int r = 0; r < 16; ++r) y[T][r] = bv;
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     f32x4 pq[4];                 // P (0, 1) and Q (2, 3) pieces of the K step being activated: channels 32 t + 16 s + 8 j + 4 hh .. + 3
     auto gather_step = [&](int t, int s) {
