@@ -1022,7 +1022,7 @@ __device__ __forceinline__ void wstage_dma(const float* __restrict__ chunk, floa
 template <typename MidHook>
 __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, const float* __restrict__ h, const float* __restrict__ agg,
                                              const float* __restrict__ vars, long nc, int nv, const float* b3, const float* b4,
-                                             const float* w3vh, const float* w3s, const float* w4t, const float* scales, float* lds,
+                                             const float* w3vh, const float* w3s, const float* w4t, const float* scales, float* lds, const float* xvl,
                                              int tid, int lane, int c, int hh, f32x16 (&yT)[4], MidHook mid_hook, bool center, float* zref PROF_ARGS) {
     // ACT_SCALE: the node rows and the Swish output enter the split GEMMs multiplied by 2^6, so that the fp16 low halves of small
     // activations stay normal (see tile_kernels.hip); every factor is a power of two folded into an existing constant.
@@ -1034,7 +1034,23 @@ __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, cons
     float xv[8];
     half8 wvf[2][4];
     f32x16 z[4][1];
-    acc_init_bias_scaled<1>(b3, sc3, hh, z);
+    // acc_init_bias_scaled<1>(b3, sc3, hh, z) with all sixteen 16-byte loads in flight at once, INTO the accumulator registers (pinned
+    // there by the empty asm), scaled in place: left to the compiler they went through one four-register temporary, four round trips
+    // to L2 one after the other at the head of every update head (the phase profile's 3.7 k cycles of "head prologue")
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b3 + 32 * T + 8 * q + 4 * hh);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) z[T][0][4 * q + m] = bv[m];
+        }
+#pragma unroll
+    for (int T = 0; T < 4; ++T) asm volatile("" : "+v"(z[T][0]));
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[T][0][r] *= sc3;
     __syncthreads();                // (with the vmcnt(0) of the LDS-DMA in flight: chunk 0 of the rows has landed)
     PROF_MARK(5);
     const int myrow = (tid >> 6) * 32 + c;
@@ -1057,9 +1073,7 @@ __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, cons
                 split8_node(v, bhi[0][s], blo[0][s]);
             }
         }
-        if (ch == 5) {      // the variables and their slot fragments are consumed after the k loop: issued two chunks ahead
-#pragma unroll
-            for (int f = 0; f < 8; ++f) xv[f] = f < nv ? tail_node_scaled(vars[(size_t)nc * nv + f]) : 0.f;
+        if (ch == 5) {      // the variables' slot fragments are consumed after the k loop: issued two chunks ahead
             const half8* wv = reinterpret_cast<const half8*>(w3vh) + lane;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -1075,6 +1089,12 @@ __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, cons
     }
     {
         half8 bx[2];
+        // the node's variables from the LDS table the kernel filled at its start (as `f < nv ? vars[...] : 0` inside the chunk loop every
+        // load sat in a branch of its own with a wait right behind it: up to eight exposed round trips per head)
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xvl + 8 * myrow), x1 = *reinterpret_cast<const f32x4*>(xvl + 8 * myrow + 4);
+        const float xr[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+        for (int f = 0; f < 8; ++f) xv[f] = tail_node_scaled(xr[f]);
         var_slot_frags(xv, hh, bx);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -1217,11 +1237,12 @@ template <bool GATED>
 __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
     // ONE LDS object: with several __shared__ arrays the compiler tags every access with its array and then makes each ds_read of an
     // array wait (vmcnt) for the LDS-DMA into that array issued just before it -- the next chunk's, i.e. the prefetch was waited for at once
-    __shared__ __attribute__((aligned(16))) float smem[2 * SPLIT_CHUNK_FLOATS + 2 * ROWBUF_FLOATS + 9 * H];
+    __shared__ __attribute__((aligned(16))) float smem[2 * SPLIT_CHUNK_FLOATS + 2 * ROWBUF_FLOATS + 9 * H + 8 * 128];
     float* const lds = smem;
     float* const rowbuf = smem + 2 * SPLIT_CHUNK_FLOATS;        // two staged 32-column chunks of the graph's node rows
     float* const part = rowbuf + 2 * ROWBUF_FLOATS;
     float* const tot = part + 8 * H;
+    float* const xvl = tot + H;                                 // the graph's variables, [row 128][8] (zero past nv and past the graph)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     const int n0 = a.graph_ptr[blockIdx.x], n1 = a.graph_ptr[blockIdx.x + 1];
@@ -1231,10 +1252,16 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
     const long nc = n < n1 ? n : n1 - 1;
 
     PROF_DECL
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // (visible to every wave behind the first head's first barrier)
+        const int e = tid + 256 * i, row = e >> 3, f = e & 7;
+        const float v = a.vars[(size_t)min(n0 + row, n1 - 1) * a.nv + min(f, a.nv - 1)];
+        xvl[e] = v * (row < cnt && f < a.nv ? 1.0f : 0.f);        // (a product, not a select of the loaded value: the compiler turns that into a branch around the load, with the wait behind it)
+    }
     f32x16 tau[4];
     if (GATED) {
         tail_rows_issue(a.h, a.agg[1], n0, n1, 0, rowbuf, tid);
-        head_compute(rowbuf, n0, n1, a.h, a.agg[1], a.vars, nc, a.nv, a.b3[1], a.b4[1], a.w3vh[1], a.w3s[1], a.w4t[1], a.scales[1], lds, tid, lane,
+        head_compute(rowbuf, n0, n1, a.h, a.agg[1], a.vars, nc, a.nv, a.b3[1], a.b4[1], a.w3vh[1], a.w3s[1], a.w4t[1], a.scales[1], lds, xvl, tid, lane,
                      c, hh, tau, [&] { tail_rows_issue(a.h, a.agg[0], n0, n1, 0, rowbuf, tid); }, true, tot PROF_PASS);
         PROF_MARK(0);
         tile_t_instance_norm(tau, wave, cnt, uniform_ro(a.scales[1], 7) * (1.0f / TAIL_ACT_SCALE), a.eps, part, tot, tid, c, hh, a.status);
@@ -1247,7 +1274,7 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
         tail_rows_issue(a.h, a.agg[0], n0, n1, 0, rowbuf, tid);
     }
     f32x16 y[4];
-    head_compute(rowbuf, n0, n1, a.h, a.agg[0], a.vars, nc, a.nv, a.b3[0], a.b4[0], a.w3vh[0], a.w3s[0], a.w4t[0], a.scales[0], lds, tid, lane, c, hh,
+    head_compute(rowbuf, n0, n1, a.h, a.agg[0], a.vars, nc, a.nv, a.b3[0], a.b4[0], a.w3vh[0], a.w3s[0], a.w4t[0], a.scales[0], lds, xvl, tid, lane, c, hh,
                  y, [] {}, GATED || a.mode == MSMP_LAYER_LIN, tot PROF_PASS);
     PROF_MARK(2);
     // this lane's piece of the transposed tiles: nodes n0 + 32 wave + acc_row(r, hh), channels 4 c .. 4 c + 3 (tile T = channel 4 c + T)
@@ -1270,12 +1297,6 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
             }
         }
     }
-    if (need_h) {       // range sentinel: tail_node_scaled saturates h silently (the same rows as the update heads read)
-        float mx = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(fmaxf(fmaxf(fabsf(hx[r][0]), fabsf(hx[r][1])), fmaxf(fabsf(hx[r][2]), fabsf(hx[r][3]))), mx);
-        if (mx > NODE_RANGE) status_raise(a.status, MSMP_STATUS_NODE_SATURATED);
-    }
     float unit = uniform_ro(a.scales[0], 7) * (1.0f / TAIL_ACT_SCALE);
     if (!GATED && a.mode != MSMP_LAYER_LIN) {
 #pragma unroll
@@ -1285,6 +1306,12 @@ __global__ __launch_bounds__(256, 2) void node_tail_split_kernel(TailArgs a) {
         unit = 1.0f;
     }
     tile_t_instance_norm(y, wave, cnt, unit, a.eps, part, tot, tid, c, hh, a.status);
+    if (need_h) {       // range sentinel on the rows of the blend (checked HERE, behind the norm's barriers: right behind the loads it made them wait)
+        float mx = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(fmaxf(fmaxf(fabsf(hx[r][0]), fabsf(hx[r][1])), fmaxf(fabsf(hx[r][2]), fabsf(hx[r][3]))), mx);
+        if (mx > NODE_RANGE) status_raise(a.status, MSMP_STATUS_NODE_SATURATED);
+    }
     PROF_MARK(3);
     if (GATED) {
 #pragma unroll
