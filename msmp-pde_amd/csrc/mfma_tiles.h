@@ -155,7 +155,9 @@ __device__ __forceinline__ half2 split_lo_pair(half2 hi, f32x2 x) {
 }
 
 // orders every later reader of `v` behind two wait states after the inline-asm writes above it (see split_lo_pair)
-__device__ __forceinline__ void mfma_operand_guard(half8& v) { asm volatile("s_nop 1" : "+v"(v)); }
+// (NOT volatile: the data dependence through `v` is all the ordering needed; as a volatile asm every guard was also ordered against every
+// other one, the gather message kernel kept all its split fragments alive at once and went from 128 to 194 registers)
+__device__ __forceinline__ void mfma_operand_guard(half8& v) { asm("s_nop 1" : "+v"(v)); }
 
 __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
 #pragma unroll
@@ -196,7 +198,7 @@ __device__ __forceinline__ void split8_node(const float (&x)[8], half8& hi, half
         lo[j] = l[0];
         lo[j + 1] = l[1];
     }
-    asm volatile("s_nop 1" : "+v"(hi), "+v"(lo));      // mfma_operand_guard for both
+    asm("s_nop 1" : "+v"(hi), "+v"(lo));      // mfma_operand_guard for both
 }
 
 // Per-node scalar columns (the <= 8 equation variables) enter a split GEMM as two K=16 fp16 MFMAs.  K slot s pairs
