@@ -1102,6 +1102,7 @@ __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, cons
             for (int T = 0; T < 4; ++T) z[T][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wvf[m][T], bx[m], z[T][0], 0, 0, 0);
     }
     mid_hook();             // the row registers are free from here on
+    __builtin_amdgcn_sched_barrier(0);      // (the requests stay HERE: sunk to the barrier below, its fence waits for them where they are issued)
     PROF_MARK(10);
 #pragma unroll
     for (int T = 0; T < 4; ++T)
@@ -1150,6 +1151,7 @@ __device__ __forceinline__ void head_compute(float* rowbuf, int n0, int n1, cons
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         if (t < 3) wstage_dma(w4t + (size_t)(t + 1) * SPLIT_CHUNK_FLOATS, lds + ((t + 1) & 1) * SPLIT_CHUNK_FLOATS, tid);
+        __builtin_amdgcn_sched_barrier(0);  // (as above: the next chunk is requested at the top of the iteration, not in front of its barrier)
         half8 zhi[1][2], zlo[1][2];
         split_acc_tile<1>(z[t], zhi, zlo);
         const half8* w = reinterpret_cast<const half8*>(lds + (t & 1) * SPLIT_CHUNK_FLOATS) + lane;

@@ -11,8 +11,9 @@ L.msmp_debug_prof_lem.argtypes = [ctypes.c_void_p, ctypes.c_int]
 EDITION = int(os.environ.get('LEM_EDITION', '4'))      # 4: anti-phased three-tile kernel; 5: one wave per SIMD, two tiles (round 4)
 L.msmp_tune(b'lem', EDITION)
 bsz = 2048
-case = make_case('E2', bsz, seed=1, device='cuda', dtype=torch.float32)
-model = mp.MODEL_NAMES['MSMP-PDE'](case.pde, time_window=25, eq_variables=EXPERIMENTS['E2'], hidden_layer=1).cuda().eval()
+EXP, MODEL = os.environ.get('LEM_EXP', 'E2'), os.environ.get('LEM_MODEL', 'MSMP-PDE')       # e.g. LEM_EXP=MSWG3 LEM_MODEL=MSMP-PDE2D
+case = make_case(EXP, bsz, seed=1, device='cuda', dtype=torch.float32)
+model = mp.MODEL_NAMES[MODEL](case.pde, time_window=25, eq_variables=EXPERIMENTS[EXP], hidden_layer=1).cuda().eval()
 data, labels = case.creator.create_data(case.u_super, [50] * bsz)
 graph = case.creator.create_graph(data, labels, case.x, case.variables, [50] * bsz)
 with torch.no_grad():
