@@ -309,11 +309,7 @@ __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int spl
     const float* bcol4 = colptr(4, keep4, ones4, bld4);
     const int n_blocks = (r1 - r0 + 15) / 16;            // the last one may be ragged: it takes the predicated loads
     const int n_full = (r1 - r0) / 16;
-#if MSMP_TILE_VARIANT == 31
-    GwRegs cur, nxt, nx2;
-#else
     GwRegs cur, nxt;
-#endif
     auto load_block = [&](int blk, GwRegs& dst) {
         const int rb = r0 + 16 * blk + 8 * kk;
         if (blk < n_full) gw_load<true>(j, acol, bcol, bld, bcol4, bld4, (blk & 3) == wave, rb, 8, dst);
@@ -321,10 +317,6 @@ __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int spl
     };
     GWP_DECL
     if (n_blocks > 0) load_block(0, cur);
-#if MSMP_TILE_VARIANT == 31
-    if (n_blocks > 1) load_block(1, nxt);
-#endif
-#if MSMP_TILE_VARIANT != 32
     // The first block's values are pinned in registers HERE (an empty asm that "modifies" them: the loads must have landed).  Without it
     // the loop header inherits "loads pending on cur" from this prologue, and the wait the compiler places at the top of the loop for the
     // first trip (vmcnt(14) ... vmcnt(0) through the publish phase) is executed on EVERY trip -- where the youngest loads are the next
@@ -332,14 +324,9 @@ __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int spl
     // 5 000 cycles per block).
 #pragma unroll
     for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(cur.a[i]), "+v"(cur.b[i]), "+v"(cur.b4[i]));
-#endif
     __builtin_amdgcn_sched_barrier(0);
     for (int blk = 0; blk < n_blocks; ++blk) {
-#if MSMP_TILE_VARIANT == 31
-        if (blk + 2 < n_blocks) load_block(blk + 2, nx2);
-#else
         if (blk + 1 < n_blocks) load_block(blk + 1, nxt);
-#endif
         __builtin_amdgcn_sched_barrier(0);               // all loads of the next block are requested before this block's work
         GWP(0);
         u32x4* fb = frags + (size_t)(blk & 1) * GW_FRAG_U4;
@@ -354,10 +341,6 @@ __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int spl
         GWP(3);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { cur.a[i] = nxt.a[i]; cur.b[i] = nxt.b[i]; cur.b4[i] = nxt.b4[i]; }
-#if MSMP_TILE_VARIANT == 31
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { nxt.a[i] = nx2.a[i]; nxt.b[i] = nx2.b[i]; nxt.b4[i] = nx2.b4[i]; }
-#endif
     }
     GWP(4);
     GWP_FLUSH
@@ -369,11 +352,7 @@ __device__ __forceinline__ void grad_weight_body(const GradWeightJob& j, int spl
             if (j.c0 + 32 * t < j.ldp) p[(size_t)(32 * wave + acc_row(r, kk)) * j.ldp + 32 * t + m] = acc[t][r];
 }
 
-#if MSMP_TILE_VARIANT == 31
-__global__ __launch_bounds__(256, 2) void grad_weight_kernel(GradWeightArgs a) {
-#else
 __global__ __launch_bounds__(256, 3) void grad_weight_kernel(GradWeightArgs a) {
-#endif
     int ji = 0;
 #pragma unroll
     for (int i = 1; i < GW_MAX_UNITS; ++i)
