@@ -75,3 +75,28 @@ def test_message_kernel_k_loop_waits_for_its_dma_at_the_barrier(isa):
     body, _ = kernel(isa['tile_kernels.hip'], '_ZN4msmp16edge_tile_kernelILi2ELb0E')
     dma = [w for w in wait_distances(body) if w[2]]
     assert dma and all(w[0] >= 60 for w in dma), dma
+
+
+def _regs(tok):
+    tok = tok.strip().rstrip(',')
+    m = re.match(r'v\[(\d+):(\d+)\]$', tok)
+    if m: return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r'v(\d+)$', tok)
+    return {int(m.group(1))} if m else set()
+
+
+@pytest.mark.parametrize('src', ['mlp_kernels.hip', 'tile_kernels.hip', 'lem_kernel.hip'])
+def test_no_vector_write_in_the_slot_in_front_of_an_mfma_that_reads_it(isa, src):
+    """gfx950 does not interlock a VALU write against an MFMA reading the register as SrcA / SrcB in the next issue slot (DESIGN.md 4.18,
+    profiles/r04N_mfma_operand_hazard.md).  The compiler pads its own instructions; inline asm is guarded in the source (mfma_operand_guard).
+    This checks the result: in no kernel of the file does a vector instruction write an operand of the MFMA right behind it."""
+    prev, bad = None, []
+    for line in isa[src].splitlines():
+        t = line.strip()
+        if not t or t.startswith((';', '.')) or t.endswith(':'): continue
+        if t.startswith('v_mfma') and prev and prev.startswith('v_') and not prev.startswith(('v_mfma', 'v_cmp', 'v_readlane', 'v_readfirstlane')):
+            ops = [o.strip() for o in t.split(None, 1)[1].split(',')]
+            written = _regs(prev.split(None, 1)[1].split(',')[0])
+            if written & (_regs(ops[1]) | _regs(ops[2])): bad.append((prev, t))
+        prev = t
+    assert not bad, f'{len(bad)} unguarded VALU -> MFMA operand pairs, e.g. {bad[0]}'
