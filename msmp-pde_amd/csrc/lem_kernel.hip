@@ -373,6 +373,27 @@ __device__ __forceinline__ void lem_ws_slots(const float (&x)[2 * ((P + 1) / 2)]
         }
 }
 
+// The B fragments of a step's input MFMAs from the tile's CONSTANT fragments (every slot of the static features -- pos_x, the variables,
+// the bias ones -- filled once in the prologue, the slots of the time-dependent features zero) and the step's dynamic values xd:
+// MODE 1: xd[0] = u_t (feature 1); MODE 2: xd = (u_t, u_{tw+t}, dt_cum_t + pos_t) (features 1, 2, 3).  A dynamic feature f sits in the
+// slots f (hi), P + f (lo), 2 P + f (hi) of lem_slot_feature; slot s is element s & 7 of fragment s >> 4 on the lanes with hh = (s >> 3) & 1.
+// Same halves as lem_ws_slots writes there: the same bits, for ~12 (MODE 1) / ~36 vector instructions instead of ~40 / ~80.
+template <int P, int MODE>
+__device__ __forceinline__ void lem_ws3_patch(const float (&xd)[MODE == 1 ? 1 : 3], int hh, half8 (&bx)[(3 * P + 2 + 15) / 16]) {
+    constexpr int ND = MODE == 1 ? 1 : 3;
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+        const int f = 1 + k;
+        const _Float16 h = (_Float16)xd[k];
+        const _Float16 l = (_Float16)(xd[k] - (float)h);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int s = p * P + f, m = s >> 4, hhs = (s >> 3) & 1, j = s & 7;
+            bx[m][j] = hh == hhs ? (p == 1 ? l : h) : bx[m][j];
+        }
+    }
+}
+
 __device__ __forceinline__ void lem_ws_bias(const float* bl, int hh, f32x16& acc) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -802,6 +823,7 @@ __global__ __launch_bounds__(512) void lem_encoder_ws3_kernel(LemWsArgs a) {
     // y fragments [tile 3] | z fragments [tile 3] (16 KB each) | scaled biases [512 + 256]
     __shared__ __attribute__((aligned(16))) float lds[6 * SPLIT_CHUNK_FLOATS + 768];
     __shared__ __attribute__((aligned(16))) float xconst[96 * 8];
+    __shared__ half8 bxc[3 * M * 64];            // constant input fragments of the three tiles: [tile][m][lane]  (lem_ws3_patch; MODE 1 / 2)
     // the input-column fragments (W[:, H:] and the bias slots) of every wave: kept out of the register file, which holds the
     // recurrent weights (128), three state tiles (48) and a work item's accumulators (32)
     __shared__ half8 wxl[8 * 2 * M * 64];
@@ -892,9 +914,33 @@ __global__ __launch_bounds__(512) void lem_encoder_ws3_kernel(LemWsArgs a) {
     __syncthreads();                    // the constants table and y(0) are read below
 
     // the two halves of a work item; X is a compile-time tile index
+    float xd[MODE == 1 ? 1 : 3];
+    if (MODE != 0 && tid < 192) {       // constant fragments of the tiles: the prologue's static features through lem_ws_slots, once
+        const int Xt = tid >> 6, l64 = tid & 63;
+        float xs[2 * NS];
+#pragma unroll
+        for (int f = 0; f < 2 * NS; ++f) xs[f] = xconst[8 * (32 * Xt + (l64 & 31)) + f];
+        if (MODE == 2) xs[3] = 0.f;     // (pos_t stays in the table: it is added to dt_cum_t per step)
+        half8 b0[M];
+        lem_ws_slots<P>(xs, l64 >> 5, b0);
+#pragma unroll
+        for (int m = 0; m < M; ++m) bxc[(Xt * M + m) * 64 + l64] = b0[m];
+    }
+    __syncthreads();
     auto fetch_x = [&](auto Xc, int t) {
         constexpr int X = decltype(Xc)::value;
         const long n = n0 + 32 * X + c;
+        if (MODE != 0) {
+            const long node = n < a.n_nodes ? n : a.n_nodes - 1;
+            if (MODE == 1) {
+                xd[0] = a.u[(size_t)node * a.tw + t];
+            } else {
+                xd[0] = a.u[(size_t)node * 2 * a.tw + t];
+                xd[MODE == 1 ? 0 : 1] = a.u[(size_t)node * 2 * a.tw + a.tw + t];
+                xd[MODE == 1 ? 0 : 2] = a.dt_cum[t] + xconst[8 * (32 * X + c) + 3];
+            }
+            return;
+        }
         lem_ws_load_x<P, MODE>(a, xconst + 8 * (32 * X + c), n < a.n_nodes ? n : a.n_nodes - 1, t, xn);
     };
     auto half_m = [&](auto Xc) {
@@ -903,7 +949,13 @@ __global__ __launch_bounds__(512) void lem_encoder_ws3_kernel(LemWsArgs a) {
         // the step input fetched at the head of the PREVIOUS half-slot is first touched here: without the fence the compiler hoists its
         // fp16 split into that vector half (a few dozen instructions behind the load) and the half stalls on the load's latency
         __builtin_amdgcn_sched_barrier(0);
-        lem_ws_slots<P>(xn, hh, bx);
+        if (MODE != 0) {        // the tile's constant fragment + the step's one or three dynamic features (lem_ws3_patch)
+#pragma unroll
+            for (int m = 0; m < M; ++m) bx[m] = bxc[(X * M + m) * 64 + lane];
+            lem_ws3_patch<P, MODE>(xd, hh, bx);
+        } else {
+            lem_ws_slots<P>(xn, hh, bx);
+        }
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxw[0], bx[0], zero, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wxw[M * 64], bx[0], zero, 0, 0, 0);
